@@ -1,0 +1,55 @@
+"""Seeded synthetic corpora (csrc/corpus.c): stand-ins for enwik8/9, silesia.tar and the
+EXE/text/delta mix that BASELINE.json names -- the real files are not available offline.
+
+`fill(kind, seed, offset, n)` is random-access, so rank r of a `-p` split can produce its own
+task slice (csarc.cpp:532-543) without generating the bytes before it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+KINDS = {"text": 0, "exe": 1, "delta": 2, "random": 3, "entropy8": 4, "silesia": 5, "mix5": 6}
+# seeds fixed by SURVEY.md section 8(d)
+SEED_ENWIK8 = 0xC5C00001
+SEED_ENWIK9 = 0xC5C00002
+SEED_EXE = 0xC5C00003
+SEED_DELTA = 0xC5C00004
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcsc_corpus.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} missing: run __graft_entry__.build()")
+        _lib = C.CDLL(path)
+        _lib.csc_corpus_fill.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64]
+        _lib.csc_corpus_fill.restype = None
+    return _lib
+
+
+def fill(kind, seed: int, offset: int, n: int) -> np.ndarray:
+    """bytes [offset, offset+n) of stream (kind, seed) as a uint8 array"""
+    k = KINDS[kind] if isinstance(kind, str) else int(kind)
+    out = np.empty(n, dtype=np.uint8)
+    if n:
+        _load().csc_corpus_fill(k, seed, offset, out.ctypes.data, n)
+    return out
+
+
+def task_slices(total: int, split: int):
+    """The archiver's single-file -p split, csarc.cpp:532-543: (offset, size) per task."""
+    split = max(1, split)
+    s = total // split
+    s = max(s, 1048576) + 4
+    out, off = [], 0
+    while off < total:
+        b = min(s, total - off)
+        out.append((off, b))
+        off += b
+    return out

@@ -1,0 +1,519 @@
+// csc_host.cpp -- host side of libcsc_mi355x.so: the reference's C API (csc_enc.h) served by
+// the gfx950 kernels of csc_kernels.hip.
+//
+// What stays on the host (SURVEY.md section 3.1 puts the device boundary inside
+// CSCEncoder::Compress): the user callbacks (always on the calling thread), the 2 MiB read loop
+// (csc_enc.cpp:160-191), the run segmentation over the analyzer's per-block verdicts
+// (csc_encoder_main.cpp:85-147 -- a few integer compares per 8 KiB block plus the one
+// `>= bpb * 0.95` double compare) and the RC/BC block framing (csc_memio.cpp:83-108).  Everything
+// that touches the data -- analyzer, filters, match finder, parser, model, range/bit coder -- runs
+// in HIP kernels on state that lives in HBM.  There is NO CPU fallback: without a HIP device
+// CSCEnc_Create fails loudly and returns NULL.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "../../include/csc_mi355x.h"
+#include "csc_device.h"
+
+namespace cscmi {
+hipError_t upload_tables();
+void launch_init_state(EncState *S, hipStream_t st);
+void launch_analyze(EncState *S, uint32_t chunk_size, const double *ent_coef, hipStream_t st);
+void launch_dup_check(EncState *S, uint32_t chunk_size, uint32_t first, uint32_t count, hipStream_t st);
+void launch_encode_runs(int parser, EncState *S, const RunDesc *runs, uint32_t nruns, uint32_t reset_arena, hipStream_t st);
+}  // namespace cscmi
+
+using namespace cscmi;
+
+namespace {
+
+const uint32_t kDltIndexHost[5] = {1, 2, 3, 4, 8};   // csc_typedef.h:36
+constexpr uint32_t kMagicEnc = 0x43534345;           // "CSCE"
+constexpr int kEventPairs = 32;
+
+void *def_alloc(void *, size_t n) { return malloc(n); }   // csc_default_alloc.cpp:5-17
+void def_free(void *, void *a) { free(a); }
+ISzAlloc g_default_alloc = {def_alloc, def_free};
+
+#define HIPCHK(call)                                                                              \
+    do {                                                                                          \
+        hipError_t err__ = (call);                                                                \
+        if (err__ != hipSuccess) {                                                                \
+            fprintf(stderr, "csc-mi355x: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(err__), \
+                    __FILE__, __LINE__);                                                          \
+            return CSCMI_DEVICE_ERROR;                                                            \
+        }                                                                                         \
+    } while (0)
+
+// the 122 words of the dictionary filter -- data the stream format is defined by (csc_filters.cpp:8-38)
+const char *const kWords[122] = {
+    "ac","ad","ai","al","am","an","ar","as","at","ea","ec","ed","ee","el","en","er","es","et","id","ie",
+    "ig","il","in","io","is","it","of","ol","on","oo","or","os","ou","ow","ul","un","ur","us","ba","be",
+    "ca","ce","co","ch","de","di","ge","gh","ha","he","hi","ho","ra","re","ri","ro","rs","la","le","li",
+    "lo","ld","ll","ly","se","si","so","sh","ss","st","ma","me","mi","ne","nc","nd","ng","nt","pa","pe",
+    "ta","te","ti","to","th","tr","wa","ve",
+    "all","and","but","dow","for","had","hav","her","him","his","man","mor","not","now","one","out",
+    "she","the","was","wer","whi","whe","wit","you","any","are",
+    "that","said","with","have","this","from","were","tion",
+};
+
+// Filters::MakeWordTree, csc_filters.cpp:87-111: node numbering follows insertion order
+void build_trie(uint16_t *next, uint8_t *sym)
+{
+    memset(next, 0, sizeof(uint16_t) * 300 * 26);
+    memset(sym, 0, 300);
+    uint32_t nodes = 1;
+    uint8_t code = 0x82;
+    for (int w = 0; w < 122; w++) {
+        uint32_t pos = 0;
+        for (const char *p = kWords[w]; *p; p++) {
+            uint32_t idx = (uint32_t)(*p - 'a');
+            if (next[pos * 26 + idx]) pos = next[pos * 26 + idx];
+            else { next[pos * 26 + idx] = (uint16_t)nodes; pos = nodes; nodes++; }
+        }
+        sym[pos] = code++;
+    }
+}
+
+std::once_flag g_tables_once;
+hipError_t g_tables_err = hipSuccess;
+
+struct EncInstance {
+    uint32_t magic;
+    ISzAlloc *alloc;
+    ISeqOutStream *os;
+    CSCProps props;
+    int device;
+    hipStream_t stream;
+    EncState *d_state;
+    EncState h;                 // host mirror of the configuration + device pointers
+    RunDesc *d_runs;
+    double *d_entcoef;
+    uint8_t *d_trie;            // next (u16[7800]) + sym (u8[300])
+    // pinned staging
+    uint8_t *h_in;
+    uint8_t *h_arena;
+    BlockInfo *h_binfo;
+    RunDesc *h_runs;
+    uint32_t *h_dup;
+    uint32_t *h_small;
+    hipEvent_t ev[kEventPairs][2];
+    hipEvent_t ev_an[2];
+    // accounting
+    int64_t outsize;            // GetCompressedSize, csc_encoder_main.cpp:174
+    CSCMIStats stats;
+    int parser;
+};
+
+void free_device(EncInstance *e)
+{
+    hipSetDevice(e->device);
+    auto F = [](void *p) { if (p) hipFree(p); };
+    F(e->h.wnd); F(e->h.mfbuf); F(e->h.p_lit); F(e->h.p_delta); F(e->h.rc_buf); F(e->h.bc_buf);
+    F(e->h.inbuf); F(e->h.swapbuf); F(e->h.arena); F(e->h.binfo); F(e->h.dup_flags);
+    F(e->d_trie); F(e->d_runs); F(e->d_entcoef); F(e->d_state);
+    auto H = [](void *p) { if (p) hipHostFree(p); };
+    H(e->h_in); H(e->h_arena); H(e->h_binfo); H(e->h_runs); H(e->h_dup); H(e->h_small);
+    for (int i = 0; i < kEventPairs; i++) for (int j = 0; j < 2; j++) if (e->ev[i][j]) hipEventDestroy(e->ev[i][j]);
+    for (int j = 0; j < 2; j++) if (e->ev_an[j]) hipEventDestroy(e->ev_an[j]);
+    if (e->stream) hipStreamDestroy(e->stream);
+}
+
+template <typename T>
+hipError_t dmalloc_zero(T **p, size_t bytes, hipStream_t st)
+{
+    hipError_t err = hipMalloc((void **)p, bytes);
+    if (err != hipSuccess) { *p = nullptr; return err; }
+    return hipMemsetAsync(*p, 0, bytes, st);
+}
+
+// MemIO::WriteBlock, csc_memio.cpp:83-108: flag byte, [3-byte BE size], payload -- 2-3 Write calls
+int write_block(EncInstance *e, const uint8_t *buf, uint32_t size, uint32_t rc1bc0)
+{
+    uint8_t fb = (uint8_t)(rc1bc0 << 7);
+    if (size == e->props.csc_blocksize) fb |= (1 << 6);
+    if (e->os->Write(e->os, &fb, 1) != 1) return -1;
+    if (size != e->props.csc_blocksize) {
+        uint8_t sb[3] = {(uint8_t)(size >> 16), (uint8_t)(size >> 8), (uint8_t)size};
+        if (e->os->Write(e->os, sb, 3) != 3) return -1;
+    }
+    if (size && e->os->Write(e->os, buf, size) != size) return -1;
+    return 0;
+}
+
+// launch [a, b) of the chunk's run list
+int launch_runs(EncInstance *e, uint32_t a, uint32_t b, bool &first_launch, int &ev_used)
+{
+    if (a == b) return 0;
+    HIPCHK(hipMemcpyAsync(e->d_runs + a, e->h_runs + a, sizeof(RunDesc) * (b - a), hipMemcpyHostToDevice, e->stream));
+    bool timed = ev_used < kEventPairs;
+    if (timed) HIPCHK(hipEventRecord(e->ev[ev_used][0], e->stream));
+    launch_encode_runs(e->parser, e->d_state, e->d_runs + a, b - a, first_launch ? 1u : 0u, e->stream);
+    HIPCHK(hipGetLastError());
+    if (timed) { HIPCHK(hipEventRecord(e->ev[ev_used][1], e->stream)); ev_used++; }
+    e->stats.encode_launches++;
+    first_launch = false;
+    return 0;
+}
+
+// read the finished coder blocks of this chunk back and hand them to the user's stream
+int drain_arena(EncInstance *e, int ev_used)
+{
+    HIPCHK(hipMemcpyAsync(e->h_small, &e->d_state->arena_used, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < ev_used; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e->ev[i][0], e->ev[i][1]) == hipSuccess) e->stats.encode_kernel_ms += ms;
+    }
+    uint32_t used = e->h_small[0], err = e->h_small[1];
+    if (err != ERR_NONE) {
+        fprintf(stderr, "csc-mi355x: device encoder error %u (%s)\n", err,
+                err == ERR_ARENA_FULL ? "output arena exhausted" : "bad block type");
+        return CSCMI_DEVICE_ERROR;
+    }
+    if (used) {
+        HIPCHK(hipMemcpyAsync(e->h_arena, e->h.arena, used, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    for (uint32_t off = 0; off < used;) {
+        const ArenaRec *rec = (const ArenaRec *)(e->h_arena + off);
+        e->outsize += rec->size;
+        e->stats.output_bytes += rec->size;
+        if (write_block(e, e->h_arena + off + 16, rec->size, rec->kind) < 0) return WRITE_ERROR;
+        off += 16 + ((rec->size + 15) & ~15u);
+    }
+    return 0;
+}
+
+// CSCEncoder::Compress, csc_encoder_main.cpp:85-147, with the data work on the device
+int encode_chunk(EncInstance *e, const void *src, size_t size, bool on_device)
+{
+    if (size == 0 || size > e->props.raw_blocksize) return size ? -1 : 0;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->h.inbuf, src, size, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+    const uint32_t csize = (uint32_t)size;
+    const uint32_t nblk = (csize + kMinBlock - 1) / kMinBlock;
+    const bool use_filters = (e->props.DLTFilter + e->props.EXEFilter + e->props.TXTFilter) != 0;   // csc_encoder_main.cpp:27-31
+    if (use_filters) {
+        HIPCHK(hipEventRecord(e->ev_an[0], e->stream));
+        launch_analyze(e->d_state, csize, e->d_entcoef, e->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(e->ev_an[1], e->stream));
+        HIPCHK(hipMemcpyAsync(e->h_binfo, e->h.binfo, sizeof(BlockInfo) * nblk, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e->ev_an[0], e->ev_an[1]) == hipSuccess) e->stats.analyze_kernel_ms += ms;
+    }
+
+    uint32_t nruns = 0, launched = 0;
+    bool first_launch = true;
+    int ev_used = 0;
+    uint32_t last_type = DT_NORMAL, last_begin = 0, last_size = 0, bpb = 0;
+    // IsDuplicateBlock results are valid only against the table state they were computed on
+    uint32_t dup_from = 0, dup_to = 0;   // blocks [dup_from, dup_to) tested since the last launch
+
+    auto close_run = [&](uint32_t tail) {
+        RunDesc &r = e->h_runs[nruns++];
+        r.type = last_type; r.offset = last_begin; r.size = last_size; r.tail = tail;
+    };
+
+    for (uint32_t blk = 0, i = 0; i < csize; blk++) {
+        uint32_t cur = csize - i < kMinBlock ? csize - i : kMinBlock;
+        uint32_t this_type = DT_NORMAL;
+        const BlockInfo *bi = use_filters ? &e->h_binfo[blk] : nullptr;
+        if (use_filters) {
+            this_type = bi->type;
+            if (this_type != DT_SKIP) bpb = bi->bpb;
+        }
+        if (this_type == DT_SKIP) this_type = last_type;
+        if (this_type != DT_NORMAL) {
+            if (this_type == DT_EXE && e->props.EXEFilter == 0) this_type = DT_NORMAL;
+            else if (this_type == DT_ENGTXT && e->props.TXTFilter == 0) this_type = DT_NORMAL;
+            else if (this_type >= DT_DLT && e->props.DLTFilter == 0) this_type = DT_NORMAL;
+        }
+        if (this_type >= DT_DLT && (double)bi->dlt_bpb[this_type - DT_DLT] >= bpb * 0.95)   // :117-121
+            this_type = DT_NORMAL;
+        if (this_type >= DT_NO_LZ) {   // :123-126 LZ::IsDuplicateBlock against the tables as of the pending run
+            if (!(launched == nruns && blk >= dup_from && blk < dup_to)) {
+                int rc = launch_runs(e, launched, nruns, first_launch, ev_used);
+                if (rc) return rc;
+                launched = nruns;
+                uint32_t cnt = 1;   // test the whole stretch of blocks that may need it under this state
+                while (blk + cnt < nblk && (e->h_binfo[blk + cnt].type >= DT_NO_LZ)) cnt++;
+                launch_dup_check(e->d_state, csize, blk, cnt, e->stream);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(e->h_dup + blk, e->h.dup_flags + blk, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost, e->stream));
+                HIPCHK(hipStreamSynchronize(e->stream));
+                dup_from = blk; dup_to = blk + cnt;
+            }
+            if (e->h_dup[blk]) this_type = DT_NORMAL;
+        }
+        if (last_type != this_type || last_size + cur > e->props.raw_blocksize) {
+            if (last_size) close_run(0);
+            last_begin = i;
+            last_size = 0;
+        }
+        last_type = this_type;
+        last_size += cur;
+        i += cur;
+    }
+    if (last_size) close_run(1);
+    int rc = launch_runs(e, launched, nruns, first_launch, ev_used);
+    if (rc) return rc;
+    e->stats.chunks++;
+    e->stats.input_bytes += size;
+    return drain_arena(e, ev_used);
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int CSCMI_DeviceCheck(void)
+{
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess || n <= 0) {
+        fprintf(stderr, "csc-mi355x: no HIP device visible (%s); this library has no CPU fallback\n",
+                err == hipSuccess ? "device count 0" : hipGetErrorString(err));
+        return CSCMI_DEVICE_ERROR;
+    }
+    return 0;
+}
+
+// CSCEncProps_Init, csc_enc.cpp:16-97 (pure host arithmetic; the 10 KiB head-room, the hash-bit
+// classes and the per-level overrides are part of the format's de-facto contract)
+void CSCEncProps_Init(CSCProps *p, uint32_t dict_size, int level)
+{
+    dict_size += 10 * kKB;
+    if (dict_size < 32 * kKB) dict_size = 32 * kKB;
+    if (dict_size > 1024 * kMB) dict_size = 1024 * kMB;
+    p->dict_size = dict_size;
+    level = level < 1 ? 1 : (level > 5 ? 5 : level);
+    p->DLTFilter = p->TXTFilter = p->EXEFilter = 1;
+    p->csc_blocksize = 64 * kKB;
+    p->raw_blocksize = 2 * kMB;
+    uint32_t hbits = dict_size < kMB ? 19 : dict_size <= 4 * kMB ? 20 : dict_size <= 16 * kMB ? 21
+                   : dict_size <= 64 * kMB ? 22 : dict_size <= 256 * kMB ? 23 : 24;
+    while (((uint32_t)1 << hbits) > dict_size) hbits--;
+    if (dict_size <= 16 * kMB) p->bt_size = dict_size;
+    else if (dict_size <= 64 * kMB) p->bt_size = (dict_size - 16 * kMB) / 2 + 16 * kMB;
+    else if (dict_size <= 256 * kMB) p->bt_size = (dict_size - 64 * kMB) / 4 + 40 * kMB;
+    else p->bt_size = (dict_size - 256 * kMB) / 8 + 88 * kMB;
+    p->good_len = 32;
+    p->hash_bits = (uint8_t)hbits;
+    p->bt_hash_bits = (uint8_t)(hbits + 1);
+    struct { uint8_t width, mode, good; int dbits; } lv[5] = {
+        {1, 2, 32, +1}, {8, 2, 24, -1}, {2, 3, 16, +1}, {8, 3, 24, -1}, {0, 3, 48, 0}};
+    const auto &L = lv[level - 1];
+    p->hash_width = L.width; p->lz_mode = L.mode; p->good_len = L.good;
+    p->hash_bits = (uint8_t)(p->hash_bits + L.dbits);
+    if (level < 5) p->bt_size = 0;          // levels 1-4 leave bt_cyc as the caller had it (:57-84)
+    else p->bt_cyc = 32;
+    if (p->bt_size == p->dict_size) p->hash_width = 0;
+}
+
+void CSCEnc_WriteProperties(const CSCProps *props, uint8_t *s, int full)   // csc_enc.cpp:145-158
+{
+    (void)full;
+    uint32_t d = (uint32_t)props->dict_size;
+    s[0] = (uint8_t)(d >> 24); s[1] = (uint8_t)(d >> 16); s[2] = (uint8_t)(d >> 8); s[3] = (uint8_t)d;
+    s[4] = (uint8_t)(props->csc_blocksize >> 16); s[5] = (uint8_t)(props->csc_blocksize >> 8); s[6] = (uint8_t)props->csc_blocksize;
+    s[7] = (uint8_t)(props->raw_blocksize >> 16); s[8] = (uint8_t)(props->raw_blocksize >> 8); s[9] = (uint8_t)props->raw_blocksize;
+}
+
+uint64_t CSCEnc_EstMemUsage(const CSCProps *p)   // csc_enc.cpp:99-112 (same 32-bit intermediate arithmetic)
+{
+    uint64_t ret = p->dict_size;
+    ret += p->csc_blocksize * 2;
+    if (p->bt_size) ret += (uint64_t)(uint32_t)((1u << p->bt_hash_bits) + 2 * p->bt_size) * sizeof(uint32_t);
+    if (p->hash_width) ret += (uint64_t)(int64_t)(int)(p->hash_width * (1 << p->hash_bits)) * sizeof(uint32_t);
+    ret += 80 * kKB * sizeof(uint32_t);
+    ret += 256 * 256 * sizeof(uint32_t) * 2;
+    ret += 2 * kMB;
+    return ret;
+}
+
+CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *outstream, ISzAlloc *alloc)   // csc_enc.cpp:114-133
+{
+    if (alloc == NULL) alloc = &g_default_alloc;
+    if (CSCMI_DeviceCheck() != 0) return NULL;
+    if (props->csc_blocksize == 0 || props->csc_blocksize >= 16 * kMB || props->raw_blocksize == 0
+        || props->raw_blocksize >= 16 * kMB || props->hash_width > 32
+        || (props->lz_mode != 1 && props->lz_mode != 2 && props->lz_mode != 3)
+        || (props->hash_width && (props->hash_bits < 1 || props->hash_bits > 28))
+        || (props->bt_size && props->bt_hash_bits && (props->bt_hash_bits > 28))) {
+        fprintf(stderr, "csc-mi355x: unsupported CSCProps\n");
+        return NULL;
+    }
+    std::call_once(g_tables_once, [] { g_tables_err = upload_tables(); });
+
+    EncInstance *e = (EncInstance *)alloc->Alloc(alloc, sizeof(EncInstance));
+    if (!e) return NULL;
+    memset(e, 0, sizeof(*e));
+    e->magic = kMagicEnc; e->alloc = alloc; e->os = outstream; e->props = *props;
+    e->parser = props->lz_mode == 3 ? 3 : 2;
+    bool ok = hipGetDevice(&e->device) == hipSuccess;
+    // each process/thread may sit on another device: the constant tables are per device
+    if (ok) ok = upload_tables() == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
+
+    EncState &h = e->h;
+    // LZ::Init / MatchFinder::Init geometry, csc_lz.cpp:15-33, csc_mf.cpp:45-106
+    uint32_t wnd = (uint32_t)(props->dict_size > 0xFFFFFFFFull ? 0xFFFFFFFFull : props->dict_size);
+    if (wnd < 32 * kKB) wnd = 32 * kKB;
+    if (wnd > 1024 * kMB) wnd = 1024 * kMB;
+    h.wnd_size = wnd;
+    h.vld_rge = wnd - kMinBlock - 4;
+    h.bsize = props->csc_blocksize; h.raw_blocksize = props->raw_blocksize;
+    h.ht_bits = props->hash_bits; h.ht_width = props->hash_width;
+    h.bt_bits = props->bt_hash_bits; h.bt_size = props->bt_size;
+    if (!h.bt_bits || !h.bt_size) h.bt_bits = h.bt_size = 0;
+    if (!h.ht_bits || !h.ht_width) h.ht_bits = h.ht_width = 0;
+    h.lz_mode = props->lz_mode; h.lz_good_len = props->good_len;
+    h.lz_bt_cyc = props->bt_cyc; h.lz_ht_cyc = props->hash_width;
+    h.mf_size = (uint64_t)kHT2Size + kHT3Size + ((uint64_t)h.ht_width << h.ht_bits);
+    if (h.bt_bits) h.mf_size += ((uint64_t)1 << h.bt_bits) + (uint64_t)h.bt_size * 2;
+    h.arena_cap = 3 * props->raw_blocksize + kMB;
+
+    hipStream_t st = e->stream;
+    ok = ok && dmalloc_zero(&h.wnd, (size_t)wnd + 256, st) == hipSuccess;               // memset(wnd_, 0, ..), csc_lz.cpp:50
+    ok = ok && dmalloc_zero(&h.mfbuf, (h.mf_size + 64) * sizeof(uint32_t), st) == hipSuccess;   // csc_mf.cpp:73
+    ok = ok && dmalloc_zero(&h.p_lit, 256 * 256 * sizeof(uint32_t), st) == hipSuccess;
+    ok = ok && dmalloc_zero(&h.p_delta, 256 * 256 * sizeof(uint32_t), st) == hipSuccess;
+    ok = ok && dmalloc_zero(&h.rc_buf, (size_t)h.bsize + 64, st) == hipSuccess;         // persistent, zero once (App. C #1)
+    ok = ok && dmalloc_zero(&h.bc_buf, (size_t)h.bsize + 64, st) == hipSuccess;
+    ok = ok && dmalloc_zero(&h.inbuf, (size_t)h.raw_blocksize + 256, st) == hipSuccess;
+    ok = ok && dmalloc_zero(&h.swapbuf, 4 * (size_t)h.raw_blocksize + 512, st) == hipSuccess;
+    ok = ok && dmalloc_zero(&h.arena, (size_t)h.arena_cap + 64, st) == hipSuccess;
+    ok = ok && dmalloc_zero(&h.binfo, sizeof(BlockInfo) * kMaxBlocksPerChunk, st) == hipSuccess;
+    ok = ok && dmalloc_zero(&h.dup_flags, sizeof(uint32_t) * kMaxBlocksPerChunk, st) == hipSuccess;
+    ok = ok && dmalloc_zero(&e->d_trie, 300 * 26 * 2 + 320, st) == hipSuccess;
+    ok = ok && dmalloc_zero(&e->d_runs, sizeof(RunDesc) * (kMaxBlocksPerChunk + 2), st) == hipSuccess;
+    ok = ok && dmalloc_zero(&e->d_entcoef, sizeof(double) * 16, st) == hipSuccess;
+    ok = ok && dmalloc_zero(&e->d_state, sizeof(EncState), st) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&e->h_in, h.raw_blocksize, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&e->h_arena, (size_t)h.arena_cap + 64, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&e->h_binfo, sizeof(BlockInfo) * kMaxBlocksPerChunk, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&e->h_runs, sizeof(RunDesc) * (kMaxBlocksPerChunk + 2), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&e->h_dup, sizeof(uint32_t) * kMaxBlocksPerChunk, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&e->h_small, 64, hipHostMallocDefault) == hipSuccess;
+    for (int i = 0; ok && i < kEventPairs; i++)
+        for (int j = 0; j < 2; j++) ok = ok && hipEventCreate(&e->ev[i][j]) == hipSuccess;
+    for (int j = 0; ok && j < 2; j++) ok = ok && hipEventCreate(&e->ev_an[j]) == hipSuccess;
+    if (!ok) {
+        fprintf(stderr, "csc-mi355x: device allocation failed (%s)\n", hipGetErrorString(hipGetLastError()));
+        free_device(e);
+        alloc->Free(alloc, e);
+        return NULL;
+    }
+    uint64_t cpos = 0;
+    h.ht2 = h.mfbuf + cpos; cpos += kHT2Size;
+    h.ht3 = h.mfbuf + cpos; cpos += kHT3Size;
+    if (h.ht_width) { h.ht6 = h.mfbuf + cpos; cpos += (uint64_t)h.ht_width << h.ht_bits; } else h.ht6 = nullptr;
+    if (h.bt_bits) { h.bt_head = h.mfbuf + cpos; cpos += (uint64_t)1 << h.bt_bits; h.bt_nodes = h.mfbuf + cpos; }
+    else { h.bt_head = nullptr; h.bt_nodes = nullptr; }
+    h.trie_next = (const uint16_t *)e->d_trie;
+    h.trie_sym = e->d_trie + 300 * 26 * 2;
+
+    // the two host-side tables: word trie, and log2(diffNum-2)-0.6 for diffNum 6..15 (csc_analyzer.cpp:223)
+    {
+        std::vector<uint8_t> trie(300 * 26 * 2 + 320, 0);
+        build_trie((uint16_t *)trie.data(), trie.data() + 300 * 26 * 2);
+        double coef[16] = {0};
+        for (int d = 6; d < 16; d++) coef[d - 6] = log((double)d - 2) / log((double)2) - 0.6;
+        ok = hipMemcpyAsync(e->d_trie, trie.data(), trie.size(), hipMemcpyHostToDevice, st) == hipSuccess
+          && hipMemcpyAsync(e->d_entcoef, coef, sizeof(coef), hipMemcpyHostToDevice, st) == hipSuccess
+          && hipMemcpyAsync(e->d_state, &h, sizeof(EncState), hipMemcpyHostToDevice, st) == hipSuccess
+          && hipStreamSynchronize(st) == hipSuccess;
+    }
+    if (ok) {
+        launch_init_state(e->d_state, st);
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess && g_tables_err == hipSuccess;
+    }
+    if (!ok) {
+        fprintf(stderr, "csc-mi355x: device initialisation failed (%s)\n", hipGetErrorString(hipGetLastError()));
+        free_device(e);
+        alloc->Free(alloc, e);
+        return NULL;
+    }
+    return (CSCEncHandle)e;
+}
+
+void CSCEnc_Destroy(CSCEncHandle p)   // csc_enc.cpp:135-143
+{
+    EncInstance *e = (EncInstance *)p;
+    if (!e || e->magic != kMagicEnc) return;
+    free_device(e);
+    e->magic = 0;
+    ISzAlloc *a = e->alloc;
+    a->Free(a, e);
+}
+
+int CSCMI_EncodeHostChunk(CSCEncHandle p, const void *host_ptr, size_t size)
+{
+    return encode_chunk((EncInstance *)p, host_ptr, size, false);
+}
+int CSCMI_EncodeDeviceChunk(CSCEncHandle p, const void *device_ptr, size_t size)
+{
+    return encode_chunk((EncInstance *)p, device_ptr, size, true);
+}
+
+// CSCEnc_Encode, csc_enc.cpp:160-191: exactly one Read of raw_blocksize per chunk; a short read
+// IS the chunk; Progress after every chunk, return value ignored.
+int CSCEnc_Encode(CSCEncHandle p, ISeqInStream *is, ICompressProgress *progress)
+{
+    EncInstance *e = (EncInstance *)p;
+    int ret = 0;
+    uint64_t insize = 0;
+    for (;;) {
+        size_t size = e->props.raw_blocksize;
+        ret = is->Read(is, e->h_in, &size);
+        if (ret >= 0 && size) {
+            insize += size;
+            ret = encode_chunk(e, e->h_in, size, false);
+            if (progress) progress->Progress(progress, insize, (uint64_t)e->outsize);
+        } else if (ret < 0) {
+            ret = READ_ERROR;
+        }
+        if (ret < 0 || size == 0) break;
+    }
+    return ret;
+}
+
+// CSCEnc_Encode_Flush, csc_enc.cpp:193-203: WriteEOF (EncodeInt(SIG_EOF)) + Coder::Flush
+int CSCEnc_Encode_Flush(CSCEncHandle p)
+{
+    EncInstance *e = (EncInstance *)p;
+    HIPCHK(hipSetDevice(e->device));
+    RunDesc &r = e->h_runs[0];
+    r.type = 0; r.offset = 0; r.size = 0; r.tail = 9;
+    bool first = true;
+    int ev_used = 0;
+    int rc = launch_runs(e, 0, 1, first, ev_used);
+    if (rc) return rc;
+    return drain_arena(e, ev_used);
+}
+
+void CSCMI_GetStats(CSCEncHandle p, CSCMIStats *out)
+{
+    EncInstance *e = (EncInstance *)p;
+    KernelStats ks;
+    memset(&ks, 0, sizeof(ks));
+    hipSetDevice(e->device);
+    if (hipMemcpy(&ks, &e->d_state->stats, sizeof(ks), hipMemcpyDeviceToHost) == hipSuccess) {
+        e->stats.find_match_calls = ks.find_match_calls; e->stats.slide_positions = ks.slide_positions;
+        e->stats.bt_steps = ks.bt_steps; e->stats.literals = ks.literals; e->stats.matches = ks.matches;
+    }
+    *out = e->stats;
+}
+
+}  // extern "C"

@@ -1,0 +1,430 @@
+// csc_kernels.hip -- gfx950 (CDNA4) kernels for the libcsc encode path.
+//
+// Design (DESIGN.md has the long form):
+//  * k_analyze / k_dup_check are wide kernels: one workgroup per 8 KiB block
+//     -- these are the embarrassingly parallel
+//    stages.
+//  * k_encode_runs is ONE wavefront per stream.  A libcsc stream is a strictly
+//    serial dependency chain (adaptive probabilities -> prices -> parse ->
+//    match-finder state), so the wavefront executes that protocol with
+//    wave-uniform control flow while its 64 lanes cooperate on the byte work
+//    inside each step: all match candidates of a position are extended at once
+//    (4 lanes x 8 bytes per candidate, __ballot + ctz), hash-bucket gathers and
+//    shift-inserts are one vector memory op, price tables and the parser's DP
+//    relaxation are filled one length per lane, and the order-1 literal coder
+//    fetches/updates its 8 probabilities in 8 lanes before the (serial)
+//    range-coder arithmetic.  Small adaptive tables, the DP nodes and the word
+//    trie live in LDS; window, hash tables / binary tree and p_lit live in HBM.
+//    Independent streams (the archiver's -p / per-extension tasks) run as
+//    independent wavefronts on other CUs / GPUs.
+//
+// No MFMA here: there is no dense contraction anywhere on this path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "csc_device.h"
+#include "csc_tables.h"
+
+namespace cscmi {
+
+#define DEV __device__ __forceinline__
+#define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+
+__device__ __constant__ uint32_t d_p2bits[512];
+__device__ __constant__ uint32_t d_logtable[513];
+
+__device__ static const uint32_t kDltIndex[5] = {1, 2, 3, 4, 8};   // csc_typedef.h:36
+
+// ------------------------------------------------------------------------------------------
+// LDS image of one stream while k_encode_runs is resident (~86 KiB of the CU's 160 KiB)
+struct EncLds {
+    uint32_t P[P_COUNT + 4];                  // small adaptive probability tables
+    uint32_t p2b[512];                        // probability -> price (1/128 bit)
+    uint32_t len_price[32], len_price_old[32];
+    uint32_t cand_len[kMFCandLimit + 2], cand_dist[kMFCandLimit + 2];   // mfcand_[], csc_mf.h:35
+    uint32_t appt_price[256], appt_dist[256]; // appt_[], per-length price table
+    uint32_t rep[4];                          // rep_dist_[4]
+    uint32_t cmp_pos[16], cmp_lim[16], cmp_res[16];
+    uint32_t ap_price[kAPLimit + 1], ap_dist[kAPLimit + 1];             // APUnit, csc_lz.h:33-41, SoA
+    uint32_t ap_rep[(kAPLimit + 1) * 4];
+    uint16_t ap_back[kAPLimit + 2], ap_next[kAPLimit + 2];
+    uint8_t ap_state[kAPLimit + 3], ap_lit[kAPLimit + 3];
+    uint16_t trie_next[300 * 26];
+    uint8_t trie_sym[304];
+};
+
+// wave-uniform scalar state of the stream (SGPR/VGPR resident; spilled back to EncState at exit)
+struct Sc {
+    EncState *S;
+    EncLds *L;
+    uint8_t *wnd;
+    uint32_t wnd_size, vld_rge;
+    uint32_t *ht2, *ht3, *ht6, *bt_head, *bt_nodes, *p_lit;
+    uint32_t ht_bits, ht_width, ht_low, ht_cyc, bt_bits, bt_size, bt_cyc, good_len;
+    uint32_t lz_good_len, lz_bt_cyc, lz_ht_cyc;
+    uint32_t bt_pos, pos, wnd_curpos;
+    uint32_t state, ctx, lp_rebuild_int;
+    uint64_t rc_low;
+    uint32_t rc_range, rc_cache, rc_cachesize, rc_size, bc_size, bc_curbits, bc_curval, bsize;
+    uint8_t *rc_buf, *bc_buf, *arena;
+    uint32_t arena_used, arena_cap, error;
+    uint32_t lane;
+    uint32_t st_find, st_slide, st_bt, st_lit, st_match;
+};
+
+DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+DEV uint32_t rdlane(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+
+// 8 bytes at an arbitrary byte address through three aligned dword loads + v_alignbyte
+DEV uint64_t load8u(const uint8_t *p)
+{
+    uintptr_t a = (uintptr_t)p;
+    uint32_t sh = (uint32_t)a & 3u;
+    const uint32_t *q = (const uint32_t *)(a & ~(uintptr_t)3);
+    uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+    uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    return ((uint64_t)hi << 32) | lo;
+}
+DEV uint32_t ldb(const uint8_t *p) { return UNI((uint32_t)*p); }
+
+// ==========================================================================================
+// output arena + coder (csc_coder.cpp, csc_memio.cpp:83-108 is finished on the host)
+
+// hand a finished RC/BC buffer to the host: header + 16-byte-lane copy
+DEV void emit_block(Sc &c, uint32_t kind, const uint8_t *buf, uint32_t size)
+{
+    uint32_t need = 16 + ((size + 15) & ~15u);
+    if (c.arena_used + need > c.arena_cap) { c.error = ERR_ARENA_FULL; return; }
+    uint8_t *dst = c.arena + c.arena_used;
+    wave_fence();   // the byte stores into buf came from uniform code; the copy below is per-lane
+    if (c.lane == 0) { ((uint32_t *)dst)[0] = kind; ((uint32_t *)dst)[1] = size; }
+    const uint4 *s4 = (const uint4 *)buf;
+    uint4 *d4 = (uint4 *)(dst + 16);
+    uint32_t n16 = (size + 15) >> 4;
+    for (uint32_t i = c.lane; i < n16; i += 64) d4[i] = s4[i];
+    c.arena_used += need;
+}
+
+DEV void rc_put(Sc &c, uint32_t byte)
+{
+    c.rc_buf[c.rc_size++] = (uint8_t)byte;
+    if (c.rc_size == c.bsize) { emit_block(c, 1, c.rc_buf, c.bsize); c.rc_size = 0; }
+}
+
+// Coder::RC_ShiftLow, csc_coder.cpp:89-112
+DEV void rc_shift_low(Sc &c)
+{
+    uint32_t low32 = (uint32_t)c.rc_low, top = (uint32_t)(c.rc_low >> 32);
+    if (low32 < 0xFF000000u || top != 0) {
+        uint32_t temp = c.rc_cache;
+        do {
+            rc_put(c, (temp + top) & 0xFF);
+            temp = 0xFF;
+        } while (--c.rc_cachesize != 0);
+        c.rc_cache = low32 >> 24;
+    }
+    c.rc_cachesize++;
+    c.rc_low = (uint64_t)(low32 << 8);
+}
+
+// arithmetic half of EncodeBit (csc_coder.h:67-81); p is the probability BEFORE its update
+DEV void rc_code(Sc &c, uint32_t v, uint32_t p)
+{
+    uint32_t bound = (c.rc_range >> 12) * p;
+    if (v) c.rc_range = bound;
+    else { c.rc_low += bound; c.rc_range -= bound; }
+    if (c.rc_range < (1u << 24)) { c.rc_range <<= 8; rc_shift_low(c); }
+}
+DEV uint32_t p_update(uint32_t v, uint32_t p) { return v ? p + ((0xFFFu - p) >> 5) : p - (p >> 5); }
+
+// EncodeBit on an LDS-resident probability
+DEV void enc_bit_lds(Sc &c, uint32_t v, uint32_t idx)
+{
+    uint32_t p = UNI(c.L->P[idx]);
+    c.L->P[idx] = p_update(v, p);
+    rc_code(c, v, p);
+}
+
+DEV void bc_put(Sc &c, uint32_t byte)
+{
+    c.bc_buf[c.bc_size++] = (uint8_t)byte;
+    if (c.bc_size == c.bsize) { emit_block(c, 0, c.bc_buf, c.bsize); c.bc_size = 0; }   // BCWCheckBound
+}
+
+// Coder::EncDirect16, csc_coder.cpp:76-87
+DEV void enc_direct16(Sc &c, uint32_t val, uint32_t len)
+{
+    c.bc_curval = (c.bc_curval << len) | val;
+    c.bc_curbits += len;
+    while (c.bc_curbits >= 8) {
+        bc_put(c, (c.bc_curval >> (c.bc_curbits - 8)) & 0xFF);
+        c.bc_curbits -= 8;
+    }
+}
+DEV void enc_direct(Sc &c, uint32_t v, uint32_t l)   // EncodeDirect, csc_coder.h:83-88
+{
+    if (l <= 16) enc_direct16(c, v, l);
+    else { enc_direct16(c, v >> 16, l - 16); enc_direct16(c, v & 0xFFFF, 16); }
+}
+
+// Coder::Flush, csc_coder.cpp:40-74: the byte at rc_buf[rc_size] is NOT stored -- it keeps
+// whatever the persistent buffer held; rc_buf is zero-initialised once.
+DEV void coder_flush(Sc &c)
+{
+    for (int i = 0; i < 5; i++) rc_shift_low(c);
+    c.rc_size++;
+    bc_put(c, (c.bc_curval << (8 - c.bc_curbits)) & 0xFF);
+    bc_put(c, 0);
+    emit_block(c, 1, c.rc_buf, c.rc_size);
+    emit_block(c, 0, c.bc_buf, c.bc_size);
+    c.rc_low = 0; c.rc_range = 0xFFFFFFFFu; c.rc_cachesize = 1; c.rc_cache = 0;
+    c.rc_size = c.bc_size = 0; c.bc_curbits = c.bc_curval = 0;
+}
+
+// ==========================================================================================
+// Model (csc_model.cpp)
+
+DEV uint32_t bit_price(const Sc &c, uint32_t v, uint32_t p)   // FEncodeBit, csc_model.cpp:161-167
+{
+    return UNI(c.L->p2b[(v ? p : 4096u - p) >> 3]);
+}
+DEV uint32_t lds_price(const Sc &c, uint32_t v, uint32_t idx) { return bit_price(c, v, UNI(c.L->P[idx])); }
+
+// Model::EncodeInt, csc_model.cpp:389-414
+DEV void encode_int(Sc &c, uint32_t num)
+{
+    uint32_t slot = num ? 31u - (uint32_t)__builtin_clz(num) : 0u;
+    enc_direct(c, slot, 5);
+    if (slot == 0) enc_direct(c, num, 1);
+    else enc_direct(c, num - (1u << slot), slot);
+}
+
+// Model::encode_matchlen_1, csc_model.cpp:113-145
+DEV void encode_matchlen_1(Sc &c, uint32_t len)
+{
+    if (len < 16) {
+        uint32_t base;
+        if (len < 8) { enc_bit_lds(c, 0, P_LEN_SLOT); base = P_LEN_X1; }
+        else { enc_bit_lds(c, 1, P_LEN_SLOT); enc_bit_lds(c, 0, P_LEN_SLOT + 1); len -= 8; base = P_LEN_X2; }
+        uint32_t cc = len | 0x08;
+        do { enc_bit_lds(c, (cc >> 2) & 1, base + (cc >> 3)); cc <<= 1; } while (cc < 0x40);
+    } else {
+        enc_bit_lds(c, 1, P_LEN_SLOT);
+        enc_bit_lds(c, 1, P_LEN_SLOT + 1);
+        len -= 16;
+        uint32_t cc = len | 0x80;
+        do { enc_bit_lds(c, (cc >> 6) & 1, P_LEN_X3 + (cc >> 7)); cc <<= 1; } while (cc < 0x4000);
+    }
+}
+
+// Model::encode_matchlen_2, csc_model.cpp:147-159
+DEV void encode_matchlen_2(Sc &c, uint32_t len)
+{
+    if (len >= 143) {
+        encode_matchlen_1(c, 143);
+        len -= 143;
+        while (len >= 143) { len -= 143; enc_bit_lds(c, 0, P_LONGLEN); }
+        enc_bit_lds(c, 1, P_LONGLEN);
+    }
+    encode_matchlen_1(c, len);
+}
+
+// 8 binary decisions of one byte under an order-1 row in HBM.  The 8 tree nodes are distinct
+// and known up front, so 8 lanes fetch + update them in one round trip; only the range-coder
+// arithmetic is serial.  (csc_model.cpp:176-183, 452-459, 504-509)
+DEV void encode_byte_tree(Sc &c, uint32_t *row, uint32_t sym)
+{
+    uint32_t cc = sym | 0x100;
+    uint32_t k = c.lane & 7;
+    uint32_t idx = cc >> (8 - k), bit = (cc >> (7 - k)) & 1;
+    uint32_t pold = row[idx];
+    if (c.lane < 8) row[idx] = p_update(bit, pold);
+#pragma unroll
+    for (int j = 0; j < 8; j++) rc_code(c, (cc >> (7 - j)) & 1, rdlane(pold, j));
+}
+
+// Model::EncodeLiteral, csc_model.cpp:169-183
+DEV void encode_literal(Sc &c, uint32_t sym)
+{
+    enc_bit_lds(c, 0, P_STATE + c.state * 3);
+    c.state = (c.state * 4) & 0x3F;
+    uint32_t *row = c.p_lit + c.ctx * 256;
+    c.ctx = sym;
+    encode_byte_tree(c, row, sym);
+    c.st_lit++;
+}
+
+// Model::GetLiteralPrice, csc_model.cpp:185-196 -- 8 lanes gather, 3 xor-shuffles reduce
+DEV uint32_t literal_price(const Sc &c, uint32_t fstate, uint32_t fctx, uint32_t sym)
+{
+    uint32_t cc = sym | 0x100;
+    uint32_t k = c.lane & 7;
+    uint32_t p = c.p_lit[fctx * 256 + (cc >> (8 - k))];
+    uint32_t bit = (cc >> (7 - k)) & 1;
+    uint32_t pr = c.L->p2b[(bit ? p : 4096u - p) >> 3];
+    pr += __shfl_xor(pr, 1);
+    pr += __shfl_xor(pr, 2);
+    pr += __shfl_xor(pr, 4);
+    return UNI(pr) + lds_price(c, 0, P_STATE + fstate * 3);
+}
+
+// Model::EncodeRep0Len1, csc_model.cpp:198-207
+DEV void encode_rep0len1(Sc &c)
+{
+    enc_bit_lds(c, 1, P_STATE + c.state * 3 + 0);
+    enc_bit_lds(c, 0, P_STATE + c.state * 3 + 1);
+    enc_bit_lds(c, 0, P_STATE + c.state * 3 + 2);
+    c.ctx = 0;
+    c.state = (c.state * 4 + 2) & 0x3F;
+    c.st_match++;
+}
+DEV uint32_t rep0len1_price(const Sc &c, uint32_t fs)   // csc_model.cpp:209-216
+{
+    return lds_price(c, 1, P_STATE + fs * 3) + lds_price(c, 0, P_STATE + fs * 3 + 1) + lds_price(c, 0, P_STATE + fs * 3 + 2);
+}
+
+// Model::EncodeRepDistMatch, csc_model.cpp:218-232
+DEV void encode_rep_match(Sc &c, uint32_t rep_idx, uint32_t match_len)
+{
+    enc_bit_lds(c, 1, P_STATE + c.state * 3 + 0);
+    enc_bit_lds(c, 0, P_STATE + c.state * 3 + 1);
+    enc_bit_lds(c, 1, P_STATE + c.state * 3 + 2);
+    uint32_t i = 1, j;
+    j = (rep_idx >> 1) & 1; enc_bit_lds(c, j, P_REPDIST + c.state * 3 + i - 1); i += i + j;
+    j = rep_idx & 1;        enc_bit_lds(c, j, P_REPDIST + c.state * 3 + i - 1);
+    encode_matchlen_2(c, match_len);
+    c.state = (c.state * 4 + 3) & 0x3F;
+    c.st_match++;
+}
+DEV uint32_t rep_dist_price(const Sc &c, uint32_t fs, uint32_t rep_idx)   // csc_model.cpp:273-284
+{
+    uint32_t ret = lds_price(c, 1, P_STATE + fs * 3) + lds_price(c, 0, P_STATE + fs * 3 + 1) + lds_price(c, 1, P_STATE + fs * 3 + 2);
+    uint32_t i = 1, j;
+    j = (rep_idx >> 1) & 1; ret += lds_price(c, j, P_REPDIST + fs * 3 + i - 1); i += i + j;
+    j = rep_idx & 1;        ret += lds_price(c, j, P_REPDIST + fs * 3 + i - 1);
+    return ret;
+}
+
+// dist_table_ slot: largest l with dist_table_[l] <= dist (binary search of csc_model.cpp:328-337;
+// dist_table_[l] = 2^(l-2)+1 for l >= 2, so it is a clz)
+DEV uint32_t dist_slot(uint32_t dist) { return dist < 3 ? dist : 33u - (uint32_t)__builtin_clz(dist - 1); }
+
+// Model::EncodeMatch, csc_model.cpp:301-366
+DEV void encode_match(Sc &c, uint32_t dist, uint32_t len)
+{
+    enc_bit_lds(c, 1, P_STATE + c.state * 3 + 0);
+    enc_bit_lds(c, 1, P_STATE + c.state * 3 + 1);
+    encode_matchlen_2(c, len);
+    uint32_t pdist_pos, sbits;
+    if (len == 0) { pdist_pos = 0; sbits = 3; }
+    else if (len <= 2) { pdist_pos = 16 * (len - 1) + 8; sbits = 4; }
+    else if (len <= 5) { pdist_pos = 32 * (len - 3) + 8 + 16 * 2; sbits = 5; }
+    else { pdist_pos = 32 * 3 + 8 + 16 * 2; sbits = 5; }
+    uint32_t slot = dist_slot(dist), cc = slot | (1u << sbits);
+    uint32_t extra_bits = slot > 2 ? slot - 2 : 0;
+    do { enc_bit_lds(c, (cc >> (sbits - 1)) & 1, P_DIST + pdist_pos + (cc >> sbits)); cc <<= 1; } while (cc < (1u << (sbits * 2)));
+    if (extra_bits) {
+        uint32_t extra_len = dist - (1u << extra_bits) - 1;
+        if (extra_bits > 4) enc_direct(c, extra_len >> 4, extra_bits - 4);
+        cc = (__brev(extra_len & 0x0Fu) >> 28) | 0x10;   // rev16_table_, csc_model.cpp:57-62
+        uint32_t base = P_DIST_EXTRA + (extra_bits - 1) * 16;
+        do { enc_bit_lds(c, (cc >> 3) & 1, base + (cc >> 4)); cc <<= 1; } while (cc < (1u << 8));
+    }
+    c.state = (c.state * 4 + 1) & 0x3F;
+    c.st_match++;
+}
+DEV uint32_t match_dist_price(const Sc &c, uint32_t fs, uint32_t dist)   // csc_model.cpp:368-387
+{
+    uint32_t l = dist_slot(dist);
+    return lds_price(c, 1, P_STATE + fs * 3) + lds_price(c, 1, P_STATE + fs * 3 + 1) + (l > 2 ? l + 2 : 2) * 128;
+}
+
+// Model::len_price_rebuild, csc_model.cpp:234-270 -- one length per lane
+DEV void len_price_rebuild(Sc &c)
+{
+    EncLds *L = c.L;
+    if (c.lane < 32) {
+        uint32_t len = c.lane, ret = 0, cc, base;
+        uint32_t s0 = L->P[P_LEN_SLOT], s1 = L->P[P_LEN_SLOT + 1];
+        if (len < 16) {
+            if (len < 8) { ret += L->p2b[(4096u - s0) >> 3]; base = P_LEN_X1; }
+            else { ret += L->p2b[s0 >> 3] + L->p2b[(4096u - s1) >> 3]; len -= 8; base = P_LEN_X2; }
+            cc = len | 0x08;
+            do {
+                uint32_t p = L->P[base + (cc >> 3)];
+                ret += L->p2b[(((cc >> 2) & 1) ? p : 4096u - p) >> 3];
+                cc <<= 1;
+            } while (cc < 0x40);
+        } else {
+            ret += L->p2b[s0 >> 3] + L->p2b[s1 >> 3];
+            len -= 16;
+            cc = len | 0x80;
+            do {
+                uint32_t p = L->P[P_LEN_X3 + (cc >> 7)];
+                ret += L->p2b[(((cc >> 6) & 1) ? p : 4096u - p) >> 3];
+                cc <<= 1;
+            } while (cc < 0x4000);
+        }
+        L->len_price[c.lane] = ret;
+    }
+    c.lp_rebuild_int = 4096;
+}
+
+// Model::CompressLiterals, csc_model.cpp:448-461
+DEV void compress_literals(Sc &c, const uint8_t *src, uint32_t size)
+{
+    encode_int(c, size);
+    for (uint32_t i = 0; i < size; i++) {
+        uint32_t sym = ldb(src + i);
+        uint32_t *row = c.p_lit + c.ctx * 256;
+        c.ctx = sym;
+        encode_byte_tree(c, row, sym);
+    }
+}
+
+// Model::CompressBad, csc_model.cpp:463-469
+DEV void compress_bad(Sc &c, const uint8_t *src, uint32_t size)
+{
+    encode_int(c, size);
+    for (uint32_t i = 0; i < size; i++) enc_direct16(c, ldb(src + i), 8);
+}
+
+// Model::CompressRLE, csc_model.cpp:471-513
+DEV void compress_rle(Sc &c, const uint8_t *src, uint32_t size)
+{
+    EncState *S = c.S;
+    uint32_t sctx = 0;
+    encode_int(c, size);
+    if (!UNI(S->p_delta_ready)) {
+        for (uint32_t i = c.lane; i < 256 * 256; i += 64) S->p_delta[i] = 2048;
+        wave_fence();
+        S->p_delta_ready = 1;
+    }
+    for (uint32_t i = 0; i < size;) {
+        uint32_t cur = ldb(src + i);
+        if (i > 0 && size - i > 3 && ldb(src + i - 1) == cur && cur == ldb(src + i + 1) && cur == ldb(src + i + 2)) {
+            uint32_t j = i + 3, len = 3;
+            while (j < size && ldb(src + j) == cur) { len++; j++; }
+            if (len > 10) {
+                sctx = cur;
+                len -= 11;
+                enc_bit_lds(c, 1, P_RLE_FLAG);
+                encode_matchlen_2(c, len);
+                i = j;
+                continue;
+            }
+        }
+        enc_bit_lds(c, 0, P_RLE_FLAG);
+        encode_byte_tree(c, S->p_delta + sctx * 256, cur);
+        sctx = cur;
+        i++;
+    }
+}
+
+#include "csc_kernels_mf.inc"
+#include "csc_kernels_lz.inc"
+#include "csc_kernels_blocks.inc"
+
+}  // namespace cscmi
