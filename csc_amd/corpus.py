@@ -43,13 +43,6 @@ def fill(kind, seed: int, offset: int, n: int) -> np.ndarray:
 
 
 def task_slices(total: int, split: int):
-    """The archiver's single-file -p split, csarc.cpp:532-543: (offset, size) per task."""
-    split = max(1, split)
-    s = total // split
-    s = max(s, 1048576) + 4
-    out, off = [], 0
-    while off < total:
-        b = min(s, total - off)
-        out.append((off, b))
-        off += b
-    return out
+    """The archiver's single-file -p split (csarc.cpp:532-543): (offset, size) per task."""
+    from .tasks import split_single_file
+    return split_single_file(total, split)

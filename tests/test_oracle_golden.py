@@ -1,0 +1,111 @@
+"""CPU tier: the oracle (plain-C restatement) against the vectors the REFERENCE produced
+(tests/golden/*.json, written by tools/make_golden.py from oracle/_ref)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+STREAMS = json.load(open(os.path.join(G, "streams.json")))
+PROPS = json.load(open(os.path.join(G, "props.json")))
+STAGES = json.load(open(os.path.join(G, "stages.json")))
+
+
+@pytest.mark.parametrize("key", sorted(STREAMS))
+def test_oracle_stream_matches_reference_vector(orc, zalloc, key):
+    name, lv = key.split("/m")
+    spec, dict_size, clamp, max_read = cases.STREAM_CASES[name]
+    data = cases.build(spec)
+    want = STREAMS[key]
+    assert len(data) == want["input_size"] and cases.digest(data) == want["input_sha256"], "input generator drifted"
+    rc, s = orc.encode(data, int(lv), dict_size, alloc=zalloc, clamp_dict=clamp, max_read=max_read)
+    assert rc == 0
+    assert len(s) == want["stream_size"]
+    assert cases.digest(s) == want["stream_sha256"]
+    if "stream_hex" in want:
+        assert s.hex() == want["stream_hex"]
+    rcd, back = orc.decode(s, alloc=zalloc)
+    assert rcd == 0 and back == data
+
+
+def test_known_answer_sizes():
+    # sizes observed from the reference CLI
+    assert STREAMS["empty/m3"]["stream_size"] == 27
+    assert STREAMS["one_byte/m1"]["stream_size"] == 46
+    assert STREAMS["zeros_8k/m3"]["stream_size"] == 54 and STREAMS["zeros_8k/m5"]["stream_size"] == 53
+    assert STREAMS["abcdefgh_64k/m3"]["stream_size"] == 983
+    assert STREAMS["random_64k/m2"]["stream_size"] > 65536       # stored via DT_BAD / 8-bit literals
+
+
+@pytest.mark.parametrize("key", sorted(PROPS))
+def test_props_init(orc, key):
+    from csc_amd.capi import CSCProps
+    d, lv = key.split("/")
+    p = CSCProps()
+    p.bt_cyc = 7
+    orc.lib.CSCEncProps_Init(C.byref(p), int(d), int(lv))
+    want = PROPS[key]
+    assert p.as_dict() == want["props"]
+    assert orc.est_mem_usage(p) == want["est_mem"]
+    assert orc.write_properties(p).hex() == want["header_hex"]
+    q = orc.read_properties(bytes.fromhex(want["header_hex"]))
+    assert (q.dict_size, q.csc_blocksize, q.raw_blocksize) == (p.dict_size, p.csc_blocksize, p.raw_blocksize)
+
+
+def test_analyzer_verdicts(orc):
+    L = orc.lib
+    L.orc_analyze_block.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.orc_dlt_bpb.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    seen = set()
+    for key, rows in STAGES["analyze"].items():
+        kind, seed = key.split("/")
+        buf = np.frombuffer(cases.build([[kind, int(seed), 0, 256 * 1024 + 300]]), dtype=np.uint8).copy()
+        for bi, i in enumerate(range(0, len(buf), 8192)):
+            blk = buf[i:i + 8192].copy()
+            bpb = C.c_uint32(0xFFFFFFFF)
+            t = L.orc_analyze_block(blk.ctypes.data, len(blk), C.byref(bpb))
+            row = [int(t), int(bpb.value)]
+            if 0x10 <= t < 0x15 or t == 0x1E:
+                row += [int(L.orc_dlt_bpb(blk.ctypes.data, len(blk), c)) for c in (1, 2, 3, 4, 8)]
+            assert row == rows[bi], (key, bi)
+            seen.add(t)
+    # the ladder's main outcomes are all exercised (Appendix E)
+    assert {1, 2, 3, 7, 8, 0x1E} <= seen and any(0x10 <= t < 0x15 for t in seen)
+
+
+def test_filters(orc):
+    L = orc.lib
+    for f in ("orc_forward_e89", "orc_inverse_e89", "orc_inverse_dict"):
+        getattr(L, f).argtypes = [C.c_void_p, C.c_uint32]
+        getattr(L, f).restype = None
+    L.orc_forward_dict.argtypes = [C.c_void_p, C.c_uint32]
+    L.orc_forward_dict.restype = C.c_uint32
+    for f in ("orc_forward_delta", "orc_inverse_delta"):
+        getattr(L, f).argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        getattr(L, f).restype = None
+    for key, want in STAGES["filters"].items():
+        kind, seed, n = key.split("/")
+        n = int(n)
+        src = cases.build([[kind, int(seed), 0, n]])
+        a = np.frombuffer(src, dtype=np.uint8).copy()
+        L.orc_forward_e89(a.ctypes.data, n)
+        assert cases.digest(a.tobytes()) == want["e89_sha256"]
+        L.orc_inverse_e89(a.ctypes.data, n)
+        assert a.tobytes() == src
+        b = np.frombuffer(src, dtype=np.uint8).copy()
+        assert L.orc_forward_dict(b.ctypes.data, n) == want["dict_ok"]
+        assert cases.digest(b.tobytes()) == want["dict_sha256"]
+        for chn in (1, 2, 3, 4, 8):
+            d = np.frombuffer(src, dtype=np.uint8).copy()
+            L.orc_forward_delta(d.ctypes.data, n, chn)
+            assert cases.digest(d.tobytes()) == want[f"delta{chn}_sha256"]
+            L.orc_inverse_delta(d.ctypes.data, n, chn)
+            assert d.tobytes() == src
+    # reject paths: < 16 KiB never transformed; > 82 % output rejected (random data)
+    assert STAGES["filters"]["text/1/16383"]["dict_ok"] == 0
+    assert STAGES["filters"]["text/1/16384"]["dict_ok"] == 1
+    assert STAGES["filters"]["random/4/70000"]["dict_ok"] == 0
