@@ -13,5 +13,15 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcsc_mi35
 
 
 def load() -> "CscLib":
-    """Bind the product library (built in-tree by __graft_entry__.build())."""
+    """Bind the product library (built in-tree by __graft_entry__.build()).
+
+    PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one
+    process cannot both own the GPU.  Importing torch first lets the dynamic loader satisfy this
+    library's `libamdhip64.so.7` dependency with the copy torch already mapped, so torch tensors,
+    torch.distributed (RCCL) and these kernels share ONE runtime.  Stand-alone C/C++ callers simply
+    get /opt/rocm's runtime."""
+    try:
+        import torch  # noqa: F401  (plumbing only: device memory, streams, torch.distributed)
+    except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+        pass
     return CscLib(LIB_PATH)
