@@ -7,8 +7,9 @@ title = sys.argv[3] if len(sys.argv) > 3 else src
 rows = []
 if src.endswith(".db"):
     c = sqlite3.connect(src)
-    for name, calls, total, avg, pct in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
-        rows.append((name, int(calls), float(total), float(avg), float(pct)))
+    tot_all = c.execute("select sum(duration) from kernels").fetchone()[0] or 1
+    for name, calls, total in c.execute("select name, count(*), sum(duration) from kernels group by name order by sum(duration) desc"):
+        rows.append((name, int(calls), float(total), float(total) / calls, 100.0 * float(total) / tot_all))
     extra = list(c.execute("select name, count(*), min(duration), max(duration), max(vgpr_count), max(sgpr_count), max(lds_size), max(grid_x), max(workgroup_x) from kernels group by name"))
 else:
     for r in csv.DictReader(open(src)):
