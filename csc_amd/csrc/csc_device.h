@@ -73,6 +73,7 @@ struct KernelStats {          // counters for bench / DESIGN.md (SURVEY section 
     unsigned long long bt_steps;
     unsigned long long literals;
     unsigned long long matches;
+    unsigned long long tm[16];   // cycle accumulators, filled only by -DCSCMI_TIMERS development builds
 };
 
 struct EncState {

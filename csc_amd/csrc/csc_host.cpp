@@ -516,4 +516,15 @@ void CSCMI_GetStats(CSCEncHandle p, CSCMIStats *out)
     *out = e->stats;
 }
 
+// development aid (tools/gpu_timers.py with the -DCSCMI_TIMERS build); zeros in the product build
+void CSCMI_DebugTimers(CSCEncHandle p, uint64_t *out16)
+{
+    EncInstance *e = (EncInstance *)p;
+    KernelStats ks;
+    memset(&ks, 0, sizeof(ks));
+    hipSetDevice(e->device);
+    (void)hipMemcpy(&ks, &e->d_state->stats, sizeof(ks), hipMemcpyDeviceToHost);
+    for (int i = 0; i < 16; i++) out16[i] = ks.tm[i];
+}
+
 }  // extern "C"

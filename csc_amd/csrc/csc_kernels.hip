@@ -70,7 +70,21 @@ struct Sc {
     uint32_t arena_used, arena_cap, error;
     uint32_t lane;
     uint32_t st_find, st_slide, st_bt, st_lit, st_match;
+#ifdef CSCMI_TIMERS
+    unsigned long long tm[16];
+#endif
 };
+
+// development-only section timers (s_memtime); compiled out of the product build
+#ifdef CSCMI_TIMERS
+#define TM_DECL unsigned long long tm__ = __builtin_readcyclecounter()
+#define TM_ADD(c, k) do { unsigned long long n__ = __builtin_readcyclecounter(); (c).tm[k] += n__ - tm__; tm__ = n__; } while (0)
+#define TM_RESET tm__ = __builtin_readcyclecounter()
+#else
+#define TM_DECL do {} while (0)
+#define TM_ADD(c, k) do {} while (0)
+#define TM_RESET do {} while (0)
+#endif
 
 DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
