@@ -110,6 +110,7 @@ struct EncState {
     uint32_t len_price[32];
     uint32_t probs[P_COUNT + 4];
     KernelStats stats;
+    uint32_t pf_sink[64];      // keeps the cache-warming loads of k_encode_runs alive
 };
 
 }  // namespace cscmi

@@ -51,6 +51,10 @@ struct EncLds {
     uint8_t ap_state[kAPLimit + 3], ap_lit[kAPLimit + 3];
     uint16_t trie_next[300 * 26];
     uint8_t trie_sym[304];
+    // the sub-block being parsed: stage[j] = wnd[stage_base + j - 16] (16 bytes of history, 48 of look-ahead)
+    uint32_t stage[(kMinBlock + 64) / 4];
+    // mailbox between the parser wavefront and the prefetch wavefront
+    volatile uint32_t hp_base, hp_cur, hp_pos0, hp_progress, hp_quit;
 };
 
 // wave-uniform scalar state of the stream (SGPR/VGPR resident; spilled back to EncState at exit)
@@ -69,6 +73,7 @@ struct Sc {
     uint8_t *rc_buf, *bc_buf, *arena;
     uint32_t arena_used, arena_cap, error;
     uint32_t lane;
+    uint32_t stage_base, stage_end;   // window positions covered by L->stage: [stage_base - 16, stage_end)
     uint32_t st_find, st_slide, st_bt, st_lit, st_match;
 #ifdef CSCMI_TIMERS
     unsigned long long tm[16];
@@ -102,6 +107,17 @@ DEV uint64_t load8u(const uint8_t *p)
     return ((uint64_t)hi << 32) | lo;
 }
 DEV uint32_t ldb(const uint8_t *p) { return UNI((uint32_t)*p); }
+
+// the same 8-byte fetch from the LDS copy of the current sub-block (window position wpos)
+DEV uint64_t stage_load8(const uint32_t *stage, uint32_t byte_idx)
+{
+    uint32_t sh = byte_idx & 3u;
+    const uint32_t *q = stage + (byte_idx >> 2);
+    uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+    uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    return ((uint64_t)hi << 32) | lo;
+}
 
 // ==========================================================================================
 // output arena + coder (csc_coder.cpp, csc_memio.cpp:83-108 is finished on the host)
