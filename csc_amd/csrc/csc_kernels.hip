@@ -28,6 +28,15 @@
 namespace cscmi {
 
 #define DEV __device__ __forceinline__
+// Everything the kernels touch outside LDS is HBM: typing those pointers as address_space(1)
+// makes the compiler emit global_* instead of flat_* memory instructions (flat ones also tick
+// lgkmcnt and cannot be told apart from LDS traffic by the waitcnt logic).
+#define GLOBAL_AS __attribute__((address_space(1)))
+typedef GLOBAL_AS uint8_t gu8;
+typedef GLOBAL_AS uint16_t gu16;
+typedef GLOBAL_AS uint32_t gu32;
+typedef uint32_t __attribute__((ext_vector_type(4))) raw_vec4;
+typedef GLOBAL_AS raw_vec4 gvec4;
 #define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 
 __device__ __constant__ uint32_t d_p2bits[512];
@@ -61,19 +70,20 @@ struct EncLds {
 struct Sc {
     EncState *S;
     EncLds *L;
-    uint8_t *wnd;
+    gu8 *wnd;
     uint32_t wnd_size, vld_rge;
-    uint32_t *ht2, *ht3, *ht6, *bt_head, *bt_nodes, *p_lit;
+    gu32 *ht2, *ht3, *ht6, *bt_head, *bt_nodes, *p_lit, *p_delta;
     uint32_t ht_bits, ht_width, ht_low, ht_cyc, bt_bits, bt_size, bt_cyc, good_len;
     uint32_t lz_good_len, lz_bt_cyc, lz_ht_cyc;
     uint32_t bt_pos, pos, wnd_curpos;
     uint32_t state, ctx, lp_rebuild_int;
     uint64_t rc_low;
     uint32_t rc_range, rc_cache, rc_cachesize, rc_size, bc_size, bc_curbits, bc_curval, bsize;
-    uint8_t *rc_buf, *bc_buf, *arena;
+    gu8 *rc_buf, *bc_buf, *arena, *swapbuf;
     uint32_t arena_used, arena_cap, error;
     uint32_t lane;
     uint32_t stage_base, stage_end;   // window positions covered by L->stage: [stage_base - 16, stage_end)
+    uint32_t cand_len_v, cand_dist_v; // mfcand_[1..]: candidate j lives in lane j of these two VGPRs
     uint32_t st_find, st_slide, st_bt, st_lit, st_match;
 #ifdef CSCMI_TIMERS
     unsigned long long tm[16];
@@ -94,19 +104,21 @@ struct Sc {
 DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 DEV uint32_t rdlane(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+// write a uniform value into one lane of a per-lane register (v_cmp + v_cndmask)
+DEV uint32_t wrlane(uint32_t val, uint32_t lane, uint32_t old) { return (threadIdx.x & 63u) == lane ? val : old; }
 
 // 8 bytes at an arbitrary byte address through three aligned dword loads + v_alignbyte
-DEV uint64_t load8u(const uint8_t *p)
+DEV uint64_t load8u(const gu8 *p)
 {
     uintptr_t a = (uintptr_t)p;
     uint32_t sh = (uint32_t)a & 3u;
-    const uint32_t *q = (const uint32_t *)(a & ~(uintptr_t)3);
+    const gu32 *q = (const gu32 *)(a & ~(uintptr_t)3);
     uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
     uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
     uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
     return ((uint64_t)hi << 32) | lo;
 }
-DEV uint32_t ldb(const uint8_t *p) { return UNI((uint32_t)*p); }
+DEV uint32_t ldb(const gu8 *p) { return UNI((uint32_t)*p); }
 
 // the same 8-byte fetch from the LDS copy of the current sub-block (window position wpos)
 DEV uint64_t stage_load8(const uint32_t *stage, uint32_t byte_idx)
@@ -123,15 +135,15 @@ DEV uint64_t stage_load8(const uint32_t *stage, uint32_t byte_idx)
 // output arena + coder (csc_coder.cpp, csc_memio.cpp:83-108 is finished on the host)
 
 // hand a finished RC/BC buffer to the host: header + 16-byte-lane copy
-DEV void emit_block(Sc &c, uint32_t kind, const uint8_t *buf, uint32_t size)
+DEV void emit_block(Sc &c, uint32_t kind, const gu8 *buf, uint32_t size)
 {
     uint32_t need = 16 + ((size + 15) & ~15u);
     if (c.arena_used + need > c.arena_cap) { c.error = ERR_ARENA_FULL; return; }
-    uint8_t *dst = c.arena + c.arena_used;
+    gu8 *dst = c.arena + c.arena_used;
     wave_fence();   // the byte stores into buf came from uniform code; the copy below is per-lane
-    if (c.lane == 0) { ((uint32_t *)dst)[0] = kind; ((uint32_t *)dst)[1] = size; }
-    const uint4 *s4 = (const uint4 *)buf;
-    uint4 *d4 = (uint4 *)(dst + 16);
+    if (c.lane == 0) { ((gu32 *)dst)[0] = kind; ((gu32 *)dst)[1] = size; }
+    const gvec4 *s4 = (const gvec4 *)buf;
+    gvec4 *d4 = (gvec4 *)(dst + 16);
     uint32_t n16 = (size + 15) >> 4;
     for (uint32_t i = c.lane; i < n16; i += 64) d4[i] = s4[i];
     c.arena_used += need;
@@ -264,7 +276,7 @@ DEV void encode_matchlen_2(Sc &c, uint32_t len)
 // 8 binary decisions of one byte under an order-1 row in HBM.  The 8 tree nodes are distinct
 // and known up front, so 8 lanes fetch + update them in one round trip; only the range-coder
 // arithmetic is serial.  (csc_model.cpp:176-183, 452-459, 504-509)
-DEV void encode_byte_tree(Sc &c, uint32_t *row, uint32_t sym)
+DEV void encode_byte_tree(Sc &c, gu32 *row, uint32_t sym)
 {
     uint32_t cc = sym | 0x100;
     uint32_t k = c.lane & 7;
@@ -280,7 +292,7 @@ DEV void encode_literal(Sc &c, uint32_t sym)
 {
     enc_bit_lds(c, 0, P_STATE + c.state * 3);
     c.state = (c.state * 4) & 0x3F;
-    uint32_t *row = c.p_lit + c.ctx * 256;
+    gu32 *row = c.p_lit + c.ctx * 256;
     c.ctx = sym;
     encode_byte_tree(c, row, sym);
     c.st_lit++;
@@ -403,32 +415,32 @@ DEV void len_price_rebuild(Sc &c)
 }
 
 // Model::CompressLiterals, csc_model.cpp:448-461
-DEV void compress_literals(Sc &c, const uint8_t *src, uint32_t size)
+DEV void compress_literals(Sc &c, const gu8 *src, uint32_t size)
 {
     encode_int(c, size);
     for (uint32_t i = 0; i < size; i++) {
         uint32_t sym = ldb(src + i);
-        uint32_t *row = c.p_lit + c.ctx * 256;
+        gu32 *row = c.p_lit + c.ctx * 256;
         c.ctx = sym;
         encode_byte_tree(c, row, sym);
     }
 }
 
 // Model::CompressBad, csc_model.cpp:463-469
-DEV void compress_bad(Sc &c, const uint8_t *src, uint32_t size)
+DEV void compress_bad(Sc &c, const gu8 *src, uint32_t size)
 {
     encode_int(c, size);
     for (uint32_t i = 0; i < size; i++) enc_direct16(c, ldb(src + i), 8);
 }
 
 // Model::CompressRLE, csc_model.cpp:471-513
-DEV void compress_rle(Sc &c, const uint8_t *src, uint32_t size)
+DEV void compress_rle(Sc &c, const gu8 *src, uint32_t size)
 {
     EncState *S = c.S;
     uint32_t sctx = 0;
     encode_int(c, size);
     if (!UNI(S->p_delta_ready)) {
-        for (uint32_t i = c.lane; i < 256 * 256; i += 64) S->p_delta[i] = 2048;
+        for (uint32_t i = c.lane; i < 256 * 256; i += 64) c.p_delta[i] = 2048;
         wave_fence();
         S->p_delta_ready = 1;
     }
@@ -447,7 +459,7 @@ DEV void compress_rle(Sc &c, const uint8_t *src, uint32_t size)
             }
         }
         enc_bit_lds(c, 0, P_RLE_FLAG);
-        encode_byte_tree(c, S->p_delta + sctx * 256, cur);
+        encode_byte_tree(c, c.p_delta + sctx * 256, cur);
         sctx = cur;
         i++;
     }
