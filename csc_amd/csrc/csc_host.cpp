@@ -28,6 +28,8 @@ void launch_init_state(EncState *S, hipStream_t st);
 void launch_analyze(EncState *S, uint32_t chunk_size, const double *ent_coef, hipStream_t st);
 void launch_dup_check(EncState *S, uint32_t chunk_size, uint32_t first, uint32_t count, hipStream_t st);
 void launch_encode_runs(int parser, EncState *S, const RunDesc *runs, uint32_t nruns, uint32_t reset_arena, hipStream_t st);
+void launch_encode_runs_multi(int parser, uint32_t nstreams, EncState *const *states, const RunDesc *const *runs,
+                              const uint32_t *nruns, const uint32_t *reset, hipStream_t st);
 }  // namespace cscmi
 
 using namespace cscmi;
@@ -110,7 +112,14 @@ struct EncInstance {
     int64_t outsize;            // GetCompressedSize, csc_encoder_main.cpp:174
     CSCMIStats stats;
     int parser;
+    // a chunk whose final launch is deferred to a batch launch (CSCMI_EncodeDeviceChunkBatch)
+    uint32_t pend_a, pend_b;
+    bool pend_first;
+    int pend_ev;
+    void **d_batch;             // [3 * kMaxBatch] device arrays: states, run lists, run counts (as pointers-sized words)
+    void **h_batch;
 };
+constexpr int kMaxBatch = 2048;
 
 void free_device(EncInstance *e)
 {
@@ -118,9 +127,9 @@ void free_device(EncInstance *e)
     auto F = [](void *p) { if (p) hipFree(p); };
     F(e->h.wnd); F(e->h.mfbuf); F(e->h.p_lit); F(e->h.p_delta); F(e->h.rc_buf); F(e->h.bc_buf);
     F(e->h.inbuf); F(e->h.swapbuf); F(e->h.arena); F(e->h.binfo); F(e->h.dup_flags);
-    F(e->d_trie); F(e->d_runs); F(e->d_entcoef); F(e->d_state);
+    F(e->d_trie); F(e->d_runs); F(e->d_entcoef); F(e->d_state); F(e->d_batch);
     auto H = [](void *p) { if (p) hipHostFree(p); };
-    H(e->h_in); H(e->h_arena); H(e->h_binfo); H(e->h_runs); H(e->h_dup); H(e->h_small);
+    H(e->h_in); H(e->h_arena); H(e->h_binfo); H(e->h_runs); H(e->h_dup); H(e->h_small); H(e->h_batch);
     for (int i = 0; i < kEventPairs; i++) for (int j = 0; j < 2; j++) if (e->ev[i][j]) hipEventDestroy(e->ev[i][j]);
     for (int j = 0; j < 2; j++) if (e->ev_an[j]) hipEventDestroy(e->ev_an[j]);
     if (e->stream) hipStreamDestroy(e->stream);
@@ -192,10 +201,15 @@ int drain_arena(EncInstance *e, int ev_used)
     return 0;
 }
 
-// CSCEncoder::Compress, csc_encoder_main.cpp:85-147, with the data work on the device
-int encode_chunk(EncInstance *e, const void *src, size_t size, bool on_device)
+// CSCEncoder::Compress, csc_encoder_main.cpp:85-147, with the data work on the device.
+// Three stages so that many handles can be driven through one multi-stream launch:
+//   chunk_begin   upload the chunk, launch the analyzer, start the verdict read-back (no wait)
+//   chunk_segment wait for the verdicts, build the run list (may launch + wait for duplicate-block
+//                 checks), then either launch the remaining runs or leave them pending
+//   chunk_finish  read the coder blocks back and call the user's Write
+int chunk_begin(EncInstance *e, const void *src, size_t size, bool on_device)
 {
-    if (size == 0 || size > e->props.raw_blocksize) return size ? -1 : 0;
+    if (size == 0 || size > e->props.raw_blocksize) return -1;
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(e->h.inbuf, src, size, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
     const uint32_t csize = (uint32_t)size;
@@ -207,7 +221,17 @@ int encode_chunk(EncInstance *e, const void *src, size_t size, bool on_device)
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(e->ev_an[1], e->stream));
         HIPCHK(hipMemcpyAsync(e->h_binfo, e->h.binfo, sizeof(BlockInfo) * nblk, hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    return 0;
+}
+
+int chunk_segment(EncInstance *e, size_t size, bool defer_final)
+{
+    const uint32_t csize = (uint32_t)size;
+    const uint32_t nblk = (csize + kMinBlock - 1) / kMinBlock;
+    const bool use_filters = (e->props.DLTFilter + e->props.EXEFilter + e->props.TXTFilter) != 0;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (use_filters) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, e->ev_an[0], e->ev_an[1]) == hipSuccess) e->stats.analyze_kernel_ms += ms;
     }
@@ -265,11 +289,25 @@ int encode_chunk(EncInstance *e, const void *src, size_t size, bool on_device)
         i += cur;
     }
     if (last_size) close_run(1);
-    int rc = launch_runs(e, launched, nruns, first_launch, ev_used);
-    if (rc) return rc;
     e->stats.chunks++;
     e->stats.input_bytes += size;
-    return drain_arena(e, ev_used);
+    if (defer_final) {
+        e->pend_a = launched; e->pend_b = nruns; e->pend_first = first_launch; e->pend_ev = ev_used;
+        return 0;
+    }
+    int rc = launch_runs(e, launched, nruns, first_launch, ev_used);
+    e->pend_ev = ev_used;
+    return rc;
+}
+
+int encode_chunk(EncInstance *e, const void *src, size_t size, bool on_device)
+{
+    if (size == 0) return 0;
+    int rc = chunk_begin(e, src, size, on_device);
+    if (rc) return rc;
+    rc = chunk_segment(e, size, false);
+    if (rc) return rc;
+    return drain_arena(e, e->pend_ev);
 }
 
 }  // namespace
@@ -465,6 +503,58 @@ int CSCMI_EncodeHostChunk(CSCEncHandle p, const void *host_ptr, size_t size)
 int CSCMI_EncodeDeviceChunk(CSCEncHandle p, const void *device_ptr, size_t size)
 {
     return encode_chunk((EncInstance *)p, device_ptr, size, true);
+}
+
+// Many independent streams (the archiver's -p / per-extension tasks, csarc.cpp:532-557) advanced by one
+// chunk each with ONE kernel launch: one workgroup per stream.  hs[i] encodes sizes[i] bytes at
+// device_ptrs[i]; the Write callbacks of all handles run on this thread, in handle order.
+int CSCMI_EncodeDeviceChunkBatch(int n, CSCEncHandle *hs, const void *const *device_ptrs, const size_t *sizes)
+{
+    if (n <= 0) return 0;
+    if (n > kMaxBatch) return -1;
+    EncInstance *lead = (EncInstance *)hs[0];
+    HIPCHK(hipSetDevice(lead->device));
+    if (!lead->d_batch) {
+        HIPCHK(hipMalloc((void **)&lead->d_batch, sizeof(void *) * 4 * kMaxBatch));
+        HIPCHK(hipHostMalloc((void **)&lead->h_batch, sizeof(void *) * 4 * kMaxBatch, hipHostMallocDefault));
+    }
+    int rc = 0;
+    for (int i = 0; i < n && !rc; i++) rc = sizes[i] ? chunk_begin((EncInstance *)hs[i], device_ptrs[i], sizes[i], true) : 0;
+    for (int i = 0; i < n && !rc; i++) rc = sizes[i] ? chunk_segment((EncInstance *)hs[i], sizes[i], true) : 0;
+    if (rc) return rc;
+    // one launch per parser flavour over every handle that still has runs pending
+    for (int parser = 2; parser <= 3; parser++) {
+        uint32_t m = 0;
+        EncState **st = (EncState **)lead->h_batch;
+        const RunDesc **rl = (const RunDesc **)(lead->h_batch + kMaxBatch);
+        uint32_t *cnt = (uint32_t *)(lead->h_batch + 2 * kMaxBatch);
+        uint32_t *rst = (uint32_t *)(lead->h_batch + 3 * kMaxBatch);
+        for (int i = 0; i < n; i++) {
+            EncInstance *e = (EncInstance *)hs[i];
+            if (!sizes[i] || e->parser != parser || e->pend_a == e->pend_b) continue;
+            HIPCHK(hipMemcpyAsync(e->d_runs + e->pend_a, e->h_runs + e->pend_a, sizeof(RunDesc) * (e->pend_b - e->pend_a),
+                                  hipMemcpyHostToDevice, lead->stream));
+            st[m] = e->d_state; rl[m] = e->d_runs + e->pend_a; cnt[m] = e->pend_b - e->pend_a; rst[m] = e->pend_first ? 1u : 0u;
+            m++;
+        }
+        if (!m) continue;
+        HIPCHK(hipMemcpyAsync(lead->d_batch, lead->h_batch, sizeof(void *) * 4 * kMaxBatch, hipMemcpyHostToDevice, lead->stream));
+        HIPCHK(hipEventRecord(lead->ev[0][0], lead->stream));
+        launch_encode_runs_multi(parser, m, (EncState *const *)lead->d_batch, (const RunDesc *const *)(lead->d_batch + kMaxBatch),
+                                 (const uint32_t *)(lead->d_batch + 2 * kMaxBatch), (const uint32_t *)(lead->d_batch + 3 * kMaxBatch), lead->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(lead->ev[0][1], lead->stream));
+        HIPCHK(hipStreamSynchronize(lead->stream));
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, lead->ev[0][0], lead->ev[0][1]) == hipSuccess) lead->stats.encode_kernel_ms += ms;
+        lead->stats.encode_launches++;
+    }
+    for (int i = 0; i < n; i++) {
+        if (!sizes[i]) continue;
+        int r = drain_arena((EncInstance *)hs[i], 0);
+        if (r && !rc) rc = r;
+    }
+    return rc;
 }
 
 // CSCEnc_Encode, csc_enc.cpp:160-191: exactly one Read of raw_blocksize per chunk; a short read

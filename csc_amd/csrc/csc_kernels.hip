@@ -45,21 +45,21 @@ __device__ __constant__ uint32_t d_logtable[513];
 __device__ static const uint32_t kDltIndex[5] = {1, 2, 3, 4, 8};   // csc_typedef.h:36
 
 // ------------------------------------------------------------------------------------------
-// LDS image of one stream while k_encode_runs is resident (~86 KiB of the CU's 160 KiB)
+// LDS image of one stream while k_encode_runs is resident (~79 KiB: two streams per CU fit in 160 KiB)
 struct EncLds {
     uint32_t P[P_COUNT + 4];                  // small adaptive probability tables
     uint32_t p2b[512];                        // probability -> price (1/128 bit)
     uint32_t len_price[32], len_price_old[32];
-    uint32_t cand_len[kMFCandLimit + 2], cand_dist[kMFCandLimit + 2];   // mfcand_[], csc_mf.h:35
     uint32_t appt_price[256], appt_dist[256]; // appt_[], per-length price table
     uint32_t rep[4];                          // rep_dist_[4]
     uint32_t cmp_pos[16], cmp_lim[16], cmp_res[16];
     uint32_t ap_price[kAPLimit + 1], ap_dist[kAPLimit + 1];             // APUnit, csc_lz.h:33-41, SoA
-    uint32_t ap_rep[(kAPLimit + 1) * 4];
+    union {                                   // the word trie is only needed while the dictionary filter runs,
+        uint32_t ap_rep[(kAPLimit + 1) * 4];  // the DP nodes only while the parser runs: they share LDS
+        struct { uint16_t trie_next[300 * 26]; uint8_t trie_sym[304]; };
+    };
     uint16_t ap_back[kAPLimit + 2], ap_next[kAPLimit + 2];
     uint8_t ap_state[kAPLimit + 3], ap_lit[kAPLimit + 3];
-    uint16_t trie_next[300 * 26];
-    uint8_t trie_sym[304];
     // the sub-block being parsed: stage[j] = wnd[stage_base + j - 16] (16 bytes of history, 48 of look-ahead)
     uint32_t stage[(kMinBlock + 64) / 4];
     // mailbox between the parser wavefront and the prefetch wavefront

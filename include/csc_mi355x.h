@@ -94,6 +94,9 @@ typedef struct {
 /* Same as one iteration of CSCEnc_Encode's read loop (csc_enc.cpp:170-181), but the <= raw_blocksize
  * chunk is already resident in device memory (bench.py keeps inputs in HBM).  Returns 0 or an error. */
 int CSCMI_EncodeDeviceChunk(CSCEncHandle p, const void *device_ptr, size_t size);
+/* n independent handles (tasks of a -p / per-extension split) advanced by one chunk each with ONE kernel
+ * launch, one workgroup per stream; handles must live on the current device.  sizes[i] == 0 skips handle i. */
+int CSCMI_EncodeDeviceChunkBatch(int n, CSCEncHandle *hs, const void *const *device_ptrs, const size_t *sizes);
 /* Host-memory variant used by CSCEnc_Encode itself. */
 int CSCMI_EncodeHostChunk(CSCEncHandle p, const void *host_ptr, size_t size);
 void CSCMI_GetStats(CSCEncHandle p, CSCMIStats *out);

@@ -167,3 +167,37 @@ def test_two_handles_interleaved(prod):
         L.CSCEnc_Destroy(h)
         outs.append(bytes(w.out))
     assert outs[0] == prod.encode(a, 3, len(a))[1] and outs[1] == prod.encode(b, 3, len(b))[1]
+
+
+def test_batch_of_streams_equals_one_by_one(prod):
+    """CSCMI_EncodeDeviceChunkBatch: 12 task streams (a -p12 split incl. a short last slice and an EXE-typed one)
+    advanced chunk by chunk with one launch per step == each stream encoded alone."""
+    import torch
+    from csc_amd import corpus, tasks
+    from csc_amd.capi import BytesWriter
+    L = prod.lib
+    L.CSCMI_EncodeDeviceChunkBatch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    total = 12 * 2500000 + 777
+    sl = tasks.split_single_file(total, 12)
+    datas = [corpus.fill("exe" if i == 3 else "text", 900 + i, off, n).tobytes() for i, (off, n) in enumerate(sl)]
+    hs, ws, devs = [], [], []
+    for d in datas:
+        p = prod.props_init(len(d), 3)
+        w = BytesWriter()
+        h = L.CSCEnc_Create(C.byref(p), C.cast(w.ptr(), C.c_void_p), None)
+        assert h
+        w.out += prod.write_properties(p)
+        hs.append(h); ws.append(w)
+        devs.append(torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda())
+    torch.cuda.synchronize()
+    n = len(hs)
+    H = (C.c_void_p * n)(*hs)
+    for k in range(2):
+        Z = [max(0, min(2097152, len(d) - k * 2097152)) for d in datas]
+        P = (C.c_void_p * n)(*[t.data_ptr() + k * 2097152 for t in devs])
+        assert L.CSCMI_EncodeDeviceChunkBatch(n, H, P, (C.c_size_t * n)(*Z)) == 0
+    for h in hs:
+        assert L.CSCEnc_Encode_Flush(h) == 0
+        L.CSCEnc_Destroy(h)
+    for d, w in zip(datas, ws):
+        assert bytes(w.out) == prod.encode(d, 3, len(d))[1]
