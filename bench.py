@@ -73,54 +73,60 @@ def cpu_baseline(data, level, dict_size, task_size, sample_bytes):
             "seconds": round(dt, 2), "ratio": round(len(stream) / max(1, len(sample)), 4)}, stream
 
 
-def multi_stream_job(lib, S, level, dict_size):
-    """Secondary measurement (stderr, not the contract line): the archiver's task split is where this
-    path shards, so one GPU can run every task of `csarc a -m3 -d64m -p<S>` at once -- one workgroup
-    per task through CSCMI_EncodeDeviceChunkBatch.  Encodes the whole 10^9-byte stand-in."""
+def multi_stream_job(lib, stream_counts, level, dict_size):
+    """Secondary measurement (extra `multi_stream` field of the JSON line, never `value`): the archiver's
+    task split is where this path shards, so one GPU can run every task of `csarc a -m3 -d64m -p<S>` at
+    once -- one workgroup per task through CSCMI_EncodeDeviceChunkBatch.  Each entry encodes the WHOLE
+    10^9-byte stand-in.  S = 127 is the largest -p the reference CLI accepts for one file (u8 nfrags)."""
     import hashlib
     import torch
     from csc_amd import corpus
     from csc_amd.capi import BytesWriter
     L = lib.lib
     L.CSCMI_EncodeDeviceChunkBatch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
-    slices = corpus.task_slices(TOTAL, S)
-    S = len(slices)
-    hs, ws, devs = [], [], []
-    for off, n in slices:
-        props = lib.props_init(min(dict_size, n), level)
-        w = BytesWriter()
-        h = L.CSCEnc_Create(C.byref(props), C.cast(w.ptr(), C.c_void_p), None)
-        if not h:
-            return {"multi_stream": "CSCEnc_Create failed"}
-        w.out += lib.write_properties(props)
-        hs.append(h); ws.append(w)
-        devs.append(torch.from_numpy(corpus.fill("text", corpus.SEED_ENWIK9, off, n)).cuda())
+    whole = torch.from_numpy(corpus.fill("text", corpus.SEED_ENWIK9, 0, TOTAL)).cuda()
     chunk = 2 << 20
-    H = (C.c_void_p * S)(*hs)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    total, k = 0, 0
-    while True:
-        Z = [max(0, min(chunk, n - k * chunk)) for _, n in slices]
-        if not any(Z):
-            break
-        P = (C.c_void_p * S)(*[d.data_ptr() + k * chunk for d in devs])
-        rc = L.CSCMI_EncodeDeviceChunkBatch(S, H, P, (C.c_size_t * S)(*Z))
-        if rc != 0:
-            return {"multi_stream": f"batch encode failed rc={rc}"}
-        total += sum(Z)
-        k += 1
-    for h in hs:
-        L.CSCEnc_Encode_Flush(h)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    out = sum(len(w.out) for w in ws)
-    digest = hashlib.sha256(b"".join(hashlib.sha256(bytes(w.out)).digest() for w in ws)).hexdigest()
-    for h in hs:
-        L.CSCEnc_Destroy(h)
-    return {"multi_stream": {"what": f"whole enwik9 stand-in (10^9 B) as csarc -m{level} -d64m -p{S}: {S} independent task streams, one workgroup each, 1 GPU",
-                             "value": round(total / 1e6 / dt, 3), "unit": "MB/s", "seconds": round(dt, 2), "ratio": round(out / total, 4),
-                             "streams": S, "batch_steps": k, "sha256_of_stream_sha256s": digest}}
+    results = []
+    for S in stream_counts:
+        slices = corpus.task_slices(TOTAL, S)
+        S = len(slices)
+        hs, ws = [], []
+        for off, n in slices:
+            props = lib.props_init(min(dict_size, n), level)
+            w = BytesWriter()
+            h = L.CSCEnc_Create(C.byref(props), C.cast(w.ptr(), C.c_void_p), None)
+            if not h:
+                return {"multi_stream": "CSCEnc_Create failed"}
+            w.out += lib.write_properties(props)
+            hs.append(h); ws.append(w)
+        H = (C.c_void_p * S)(*hs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        total, k = 0, 0
+        while True:
+            Z = [max(0, min(chunk, n - k * chunk)) for _, n in slices]
+            if not any(Z):
+                break
+            P = (C.c_void_p * S)(*[whole.data_ptr() + off + k * chunk for off, _ in slices])
+            rc = L.CSCMI_EncodeDeviceChunkBatch(S, H, P, (C.c_size_t * S)(*Z))
+            if rc != 0:
+                return {"multi_stream": f"batch encode failed rc={rc}"}
+            total += sum(Z)
+            k += 1
+        for h in hs:
+            L.CSCEnc_Encode_Flush(h)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out = sum(len(w.out) for w in ws)
+        digest = hashlib.sha256(b"".join(hashlib.sha256(bytes(w.out)).digest() for w in ws)).hexdigest()
+        for h in hs:
+            L.CSCEnc_Destroy(h)
+        balg = ALG_BYTES.get(level, 42.0) + out / total
+        results.append({"what": f"whole enwik9 stand-in (10^9 B) as csarc -m{level} -d64m -p{S}: {S} independent task streams, one workgroup each, 1 GPU",
+                        "value": round(total / 1e6 / dt, 3), "unit": "MB/s", "seconds": round(dt, 2), "ratio": round(out / total, 4),
+                        "streams": S, "batch_launches": k, "hbm_roofline_frac": round(balg * total / dt / 1e9 / HBM_PEAK_GBS, 8),
+                        "sha256_of_stream_sha256s": digest})
+    return {"multi_stream": results}
 
 
 def main():
@@ -132,8 +138,8 @@ def main():
     ap.add_argument("--dict", default="64m")
     ap.add_argument("--cpu-sample-mib", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--multi-streams", type=int, default=508,
-                    help="extra (N=1 only): the WHOLE 10^9-byte file as a -p<S> task split, all tasks concurrently on this GPU; 0 = skip")
+    ap.add_argument("--multi-streams", default="127,954",
+                    help="extra (N=1 only): the WHOLE 10^9-byte file as -p<S> task splits, all tasks concurrently on this GPU; '' = skip")
     args = ap.parse_args()
 
     import numpy as np
@@ -257,12 +263,13 @@ def main():
             line["bit_exact_vs_cpu_baseline"] = bool(cpu_stream[:len(gpu_stream)] == gpu_stream)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
-
     L.CSCEnc_Encode_Flush(h)
     L.CSCEnc_Destroy(h)
-    if world == 1 and args.multi_streams > 0 and rank == 0:
-        print(json.dumps(multi_stream_job(lib, args.multi_streams, level, dict_size)), file=sys.stderr, flush=True)
+    if rank == 0:
+        if world == 1 and args.multi_streams:
+            # extra field, not `value`: every task of the -p<S> split at once on this one GPU
+            line.update(multi_stream_job(lib, [int(x) for x in args.multi_streams.split(",")], level, dict_size))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -45,21 +45,33 @@ __device__ __constant__ uint32_t d_logtable[513];
 __device__ static const uint32_t kDltIndex[5] = {1, 2, 3, 4, 8};   // csc_typedef.h:36
 
 // ------------------------------------------------------------------------------------------
-// LDS image of one stream while k_encode_runs is resident (~79 KiB: two streams per CU fit in 160 KiB)
+// LDS image of one stream while k_encode_runs is resident (< 40 KiB: four streams per CU fit in 160 KiB)
 struct EncLds {
     uint32_t P[P_COUNT + 4];                  // small adaptive probability tables
     uint32_t p2b[512];                        // probability -> price (1/128 bit)
     uint32_t len_price[32], len_price_old[32];
-    uint32_t appt_price[256], appt_dist[256]; // appt_[], per-length price table
-    uint32_t rep[4];                          // rep_dist_[4]
+    uint32_t rep[32];                         // [0..3] rep_dist_[4]; [4..] candidate distances of the position being searched
     uint32_t cmp_pos[16], cmp_lim[16], cmp_res[16];
-    uint32_t ap_price[kAPLimit + 1], ap_dist[kAPLimit + 1];             // APUnit, csc_lz.h:33-41, SoA
-    union {                                   // the word trie is only needed while the dictionary filter runs,
-        uint32_t ap_rep[(kAPLimit + 1) * 4];  // the DP nodes only while the parser runs: they share LDS
-        struct { uint16_t trie_next[300 * 26]; uint8_t trie_sym[304]; };
+    // The parser's DP nodes (APUnit, csc_lz.h:33-41) as a 256-slot ring + a per-node log.  A node is
+    // relabelled only from nodes before it and only up to good_len - 1 <= 254 positions ahead, so
+    // the live frontier (price, label, coder state, rep distances) fits a ring indexed by node & 255;
+    // what the back-trace needs (label, back pointer, literal) is logged when the node is visited.
+    uint32_t rg_price[256], rg_dist[256];
+    uint32_t rg_rep[256 * 4];
+    uint16_t rg_back[256];
+    uint8_t rg_state[256];
+    union {
+        struct {
+            uint32_t fin_dist[kAPLimit + 1];
+            uint16_t fin_back[kAPLimit + 2];
+            union {
+                uint16_t fin_next[kAPLimit + 2];                              // back-trace only (on the way out)
+                struct { uint32_t appt_price[256], appt_dist[256]; };        // price table beyond 64 lengths (custom good_len > 66)
+            };
+            uint8_t fin_lit[kAPLimit + 3];
+        };
+        struct { uint16_t trie_next[300 * 26]; uint8_t trie_sym[304]; };     // word trie, only while the dictionary filter runs
     };
-    uint16_t ap_back[kAPLimit + 2], ap_next[kAPLimit + 2];
-    uint8_t ap_state[kAPLimit + 3], ap_lit[kAPLimit + 3];
     // the sub-block being parsed: stage[j] = wnd[stage_base + j - 16] (16 bytes of history, 48 of look-ahead)
     uint32_t stage[(kMinBlock + 64) / 4];
     // mailbox between the parser wavefront and the prefetch wavefront
@@ -72,7 +84,9 @@ struct Sc {
     EncLds *L;
     gu8 *wnd;
     uint32_t wnd_size, vld_rge;
-    gu32 *ht2, *ht3, *ht6, *bt_head, *bt_nodes, *p_lit, *p_delta;
+    gu32 *ht2, *ht3, *ht6, *bt_head, *bt_nodes, *p_lit, *p_delta, *mfbuf;
+    uint32_t ht6_off, bth_off;       // word offsets of ht6 / bt_head inside mfbuf (ht2 at 0, ht3 at kHT2Size)
+    uint32_t gm6, gm2, gm3, gmb, gslot;   // per-lane constants of the entry gather (lane masks, destination slot)
     uint32_t ht_bits, ht_width, ht_low, ht_cyc, bt_bits, bt_size, bt_cyc, good_len;
     uint32_t lz_good_len, lz_bt_cyc, lz_ht_cyc;
     uint32_t bt_pos, pos, wnd_curpos;
