@@ -86,6 +86,7 @@ struct Sc {
     uint32_t wnd_size, vld_rge;
     gu32 *ht2, *ht3, *ht6, *bt_head, *bt_nodes, *p_lit, *p_delta, *mfbuf;
     uint32_t ht6_off, bth_off;       // word offsets of ht6 / bt_head inside mfbuf (ht2 at 0, ht3 at kHT2Size)
+    bool fast_ht;                    // hash-table-only configuration: vector replay path
     uint32_t gm6, gm2, gm3, gmb, gslot;   // per-lane constants of the entry gather (lane masks, destination slot)
     uint32_t ht_bits, ht_width, ht_low, ht_cyc, bt_bits, bt_size, bt_cyc, good_len;
     uint32_t lz_good_len, lz_bt_cyc, lz_ht_cyc;
