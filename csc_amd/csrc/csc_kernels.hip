@@ -50,7 +50,8 @@ struct EncLds {
     uint32_t P[P_COUNT + 4];                  // small adaptive probability tables
     uint32_t p2b[512];                        // probability -> price (1/128 bit)
     uint32_t len_price[32], len_price_old[32];
-    uint32_t rep[32];                         // [0..3] rep_dist_[4]; [4..] candidate distances of the position being searched
+    uint32_t rep[4];                          // rep_dist_[4] (live)
+    uint32_t cd[32];                          // candidate distances of the position being searched: 0-3 rep, 4 HT2, 5 HT3, 6 BT head, 7.. bucket
     uint32_t cmp_pos[16], cmp_lim[16], cmp_res[16];
     // The parser's DP nodes (APUnit, csc_lz.h:33-41) as a 256-slot ring + a per-node log.  A node is
     // relabelled only from nodes before it and only up to good_len - 1 <= 254 positions ahead, so
