@@ -421,6 +421,7 @@ CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *outstream, ISzA
     h.mf_size = (uint64_t)kHT2Size + kHT3Size + ((uint64_t)h.ht_width << h.ht_bits);
     if (h.bt_bits) h.mf_size += ((uint64_t)1 << h.bt_bits) + (uint64_t)h.bt_size * 2;
     h.arena_cap = 3 * props->raw_blocksize + kMB;
+    h.pad0 = getenv("CSCMI_NO_HELPER") ? 1u : 0u;   // development switch: run without the prefetch wavefront
 
     hipStream_t st = e->stream;
     ok = ok && dmalloc_zero(&h.wnd, (size_t)wnd + 256, st) == hipSuccess;               // memset(wnd_, 0, ..), csc_lz.cpp:50

@@ -53,6 +53,7 @@ struct EncLds {
     uint32_t rep[4];                          // rep_dist_[4] (live)
     uint32_t cd[32];                          // candidate distances of the position being searched: 0-3 rep, 4 HT2, 5 HT3, 6 BT head, 7.. bucket
     uint32_t cmp_pos[16], cmp_lim[16], cmp_res[16];
+    uint32_t rp4[4];                          // the four rep-index prices of the position being priced
     // The parser's DP nodes (APUnit, csc_lz.h:33-41) as a 256-slot ring + a per-node log.  A node is
     // relabelled only from nodes before it and only up to good_len - 1 <= 254 positions ahead, so
     // the live frontier (price, label, coder state, rep distances) fits a ring indexed by node & 255;
@@ -88,6 +89,7 @@ struct Sc {
     gu32 *ht2, *ht3, *ht6, *bt_head, *bt_nodes, *p_lit, *p_delta, *mfbuf;
     uint32_t ht6_off, bth_off;       // word offsets of ht6 / bt_head inside mfbuf (ht2 at 0, ht3 at kHT2Size)
     bool fast_ht;                    // hash-table-only configuration: vector replay path
+    uint32_t pr_off, pr_rmask, pr_pol;   // per-lane constants of the 12-term state price gather
     uint32_t gm6, gm2, gm3, gmb, gslot;   // per-lane constants of the entry gather (lane masks, destination slot)
     uint32_t ht_bits, ht_width, ht_low, ht_cyc, bt_bits, bt_size, bt_cyc, good_len;
     uint32_t lz_good_len, lz_bt_cyc, lz_ht_cyc;
