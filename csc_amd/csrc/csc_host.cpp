@@ -399,6 +399,11 @@ CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *outstream, ISzA
     memset(e, 0, sizeof(*e));
     e->magic = kMagicEnc; e->alloc = alloc; e->os = outstream; e->props = *props;
     e->parser = props->lz_mode == 3 ? 3 : 2;
+    {   // hash-table-only configuration (levels 1-4): the specialised kernels (bit 4 of the launch kind)
+        bool bt = props->bt_hash_bits && props->bt_size;
+        bool ht = props->hash_bits && props->hash_width;
+        if (!bt && ht && props->hash_width <= 9) e->parser |= 4;
+    }
     bool ok = hipGetDevice(&e->device) == hipSuccess;
     // each process/thread may sit on another device: the constant tables are per device
     if (ok) ok = upload_tables() == hipSuccess;
@@ -421,7 +426,6 @@ CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *outstream, ISzA
     h.mf_size = (uint64_t)kHT2Size + kHT3Size + ((uint64_t)h.ht_width << h.ht_bits);
     if (h.bt_bits) h.mf_size += ((uint64_t)1 << h.bt_bits) + (uint64_t)h.bt_size * 2;
     h.arena_cap = 3 * props->raw_blocksize + kMB;
-    h.pad0 = getenv("CSCMI_NO_HELPER") ? 1u : 0u;   // development switch: run without the prefetch wavefront
 
     hipStream_t st = e->stream;
     ok = ok && dmalloc_zero(&h.wnd, (size_t)wnd + 256, st) == hipSuccess;               // memset(wnd_, 0, ..), csc_lz.cpp:50
@@ -524,7 +528,8 @@ int CSCMI_EncodeDeviceChunkBatch(int n, CSCEncHandle *hs, const void *const *dev
     for (int i = 0; i < n && !rc; i++) rc = sizes[i] ? chunk_segment((EncInstance *)hs[i], sizes[i], true) : 0;
     if (rc) return rc;
     // one launch per parser flavour over every handle that still has runs pending
-    for (int parser = 2; parser <= 3; parser++) {
+    for (int parser = 2; parser <= 7; parser++) {
+        if ((parser & 3) < 2) continue;
         uint32_t m = 0;
         EncState **st = (EncState **)lead->h_batch;
         const RunDesc **rl = (const RunDesc **)(lead->h_batch + kMaxBatch);

@@ -76,8 +76,6 @@ struct EncLds {
     };
     // the sub-block being parsed: stage[j] = wnd[stage_base + j - 16] (16 bytes of history, 48 of look-ahead)
     uint32_t stage[(kMinBlock + 64) / 4];
-    // mailbox between the parser wavefront and the prefetch wavefront
-    volatile uint32_t hp_base, hp_cur, hp_pos0, hp_progress, hp_quit;
 };
 
 // wave-uniform scalar state of the stream (SGPR/VGPR resident; spilled back to EncState at exit)
