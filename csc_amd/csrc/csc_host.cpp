@@ -28,6 +28,7 @@ void launch_init_state(EncState *S, hipStream_t st);
 void launch_analyze(EncState *S, uint32_t chunk_size, const double *ent_coef, hipStream_t st);
 void launch_dup_check(EncState *S, uint32_t chunk_size, uint32_t first, uint32_t count, hipStream_t st);
 void launch_encode_runs(int parser, EncState *S, const RunDesc *runs, uint32_t nruns, uint32_t reset_arena, hipStream_t st);
+void launch_encode_eof(EncState *S, hipStream_t st);
 void launch_encode_runs_multi(int parser, uint32_t nstreams, EncState *const *states, const RunDesc *const *runs,
                               const uint32_t *nruns, const uint32_t *reset, hipStream_t st);
 }  // namespace cscmi
@@ -590,12 +591,9 @@ int CSCEnc_Encode_Flush(CSCEncHandle p)
 {
     EncInstance *e = (EncInstance *)p;
     HIPCHK(hipSetDevice(e->device));
-    RunDesc &r = e->h_runs[0];
-    r.type = 0; r.offset = 0; r.size = 0; r.tail = 9;
-    bool first = true;
+    launch_encode_eof(e->d_state, e->stream);
+    HIPCHK(hipGetLastError());
     int ev_used = 0;
-    int rc = launch_runs(e, 0, 1, first, ev_used);
-    if (rc) return rc;
     return drain_arena(e, ev_used);
 }
 
