@@ -1,0 +1,234 @@
+// csc_dec_device.cpp -- CSCDec_* of libcsc_mi355x.so served by k_decode_run (csc_dec_kernels.hip).
+//
+// The host thread owns the callbacks and the block framing, the GPU owns the stream state and all
+// decoding work:
+//   * MemIO::ReadBlock (csc_memio.cpp:5-81) is reproduced here read for read: when the kernel reports
+//     that it ran out of RC (or BC) bytes, blocks are read from the ISeqInStream -- flag byte, optional
+//     3-byte size, ONE Read for the payload -- until one of the wanted kind turns up; every block read
+//     on the way is uploaded to its ring on the device, which is the reference's queue of the
+//     "other" kind.
+//   * CSCDec_Decode (csc_dec.cpp:740-777) loops over Decompress calls; each is one or more launches
+//     of the resumable kernel; the decoded run is copied back and handed to ISeqOutStream::Write.
+// No CPU decoding path exists in this library.
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/csc_mi355x.h"
+#include "csc_device.h"
+
+namespace cscmi {
+void launch_decode_init(DecState *D, hipStream_t st);
+void launch_decode_run(DecState *D, hipStream_t st);
+}
+using namespace cscmi;
+
+namespace {
+
+constexpr uint32_t kMagicDec = 0x43534344;   // "CSCD"
+
+void *def_alloc(void *, size_t n) { return malloc(n); }
+void def_free(void *, void *a) { free(a); }
+ISzAlloc g_default_alloc = {def_alloc, def_free};
+
+const char kWords[122][8] = {   // csc_filters.cpp:8-38; symbol 0x82+i expands to kWords[i]
+    "ac","ad","ai","al","am","an","ar","as","at","ea","ec","ed","ee","el","en","er","es","et","id","ie",
+    "ig","il","in","io","is","it","of","ol","on","oo","or","os","ou","ow","ul","un","ur","us","ba","be",
+    "ca","ce","co","ch","de","di","ge","gh","ha","he","hi","ho","ra","re","ri","ro","rs","la","le","li",
+    "lo","ld","ll","ly","se","si","so","sh","ss","st","ma","me","mi","ne","nc","nd","ng","nt","pa","pe",
+    "ta","te","ti","to","th","tr","wa","ve",
+    "all","and","but","dow","for","had","hav","her","him","his","man","mor","not","now","one","out",
+    "she","the","was","wer","whi","whe","wit","you","any","are",
+    "that","said","with","have","this","from","were","tion",
+};
+
+struct DecInstance {
+    uint32_t magic;
+    ISzAlloc *alloc;
+    ISeqInStream *is;
+    int device;
+    hipStream_t stream;
+    DecState *d_state;
+    DecState h;               // host mirror: configuration + device pointers
+    DecState *h_read;         // pinned read-back of the whole (small) state
+    uint8_t *h_block;         // pinned staging for one block
+    uint8_t *h_out;           // pinned decoded run
+    uint32_t *h_qsize[2];     // host mirrors of the ring slot sizes
+    uint32_t avail[2], taken[2];
+    uint64_t consumed_view;   // GetCompressedSize as of the last launch
+};
+
+void free_all(DecInstance *x)
+{
+    (void)hipSetDevice(x->device);
+    auto F = [](void *p) { if (p) (void)hipFree(p); };
+    F(x->h.wnd); F(x->h.p_lit); F(x->h.out); F(x->h.swap); F(x->h.q[0]); F(x->h.q[1]);
+    F(x->h.qsize[0]); F(x->h.qsize[1]); F(x->h.undo_addr); F(x->h.undo_val); F((void *)x->h.words); F(x->d_state);
+    auto H = [](void *p) { if (p) (void)hipHostFree(p); };
+    H(x->h_read); H(x->h_block); H(x->h_out);
+    free(x->h_qsize[0]); free(x->h_qsize[1]);
+    if (x->stream) (void)hipStreamDestroy(x->stream);
+    x->magic = 0;
+    ISzAlloc *a = x->alloc;
+    a->Free(a, x);
+}
+
+// MemIO::ReadBlock for a block that is not queued yet (csc_memio.cpp:17-79): read stream blocks until one of
+// `kind` (1 RC, 0 BC) arrives; each block read goes to the device ring of its own kind.
+int read_block(DecInstance *x, int kind)
+{
+    for (;;) {
+        uint8_t fb, sb[3];
+        size_t n = 1;
+        x->is->Read(x->is, &fb, &n);
+        if (n != 1) return -1;
+        uint32_t cur = x->h.bsize;
+        if (!((fb >> 6) & 1)) {
+            n = 3;
+            x->is->Read(x->is, sb, &n);
+            if (n != 3) return -1;
+            cur = ((uint32_t)sb[0] << 16) + ((uint32_t)sb[1] << 8) + sb[2];
+        }
+        if (!cur || cur > x->h.bsize) return -1;
+        n = cur;
+        x->is->Read(x->is, x->h_block, &n);       // ONE Read per payload; a short one is an error (:47-50)
+        if (n != cur) return -1;
+        int k2 = (fb >> 7) & 1;
+        if (x->avail[k2] - x->taken[k2] >= x->h.qslots) {
+            fprintf(stderr, "csc-mi355x: decoder block ring overflow\n");
+            return -1;
+        }
+        uint32_t slot = x->avail[k2] % x->h.qslots;
+        if (hipMemcpy(x->h.q[k2] + (size_t)slot * x->h.bsize, x->h_block, cur, hipMemcpyHostToDevice) != hipSuccess) return -1;
+        x->h_qsize[k2][slot] = cur;
+        x->avail[k2]++;
+        if (k2 == kind) return 0;
+    }
+}
+
+// run the kernel until the current Decompress call is complete; returns 0 / error code, *size = run length
+int decompress(DecInstance *x, uint32_t *size)
+{
+    *size = 0;
+    for (;;) {
+        // publish what has been uploaded so far
+        for (int k = 0; k < 2; k++)
+            if (hipMemcpyAsync(x->h.qsize[k], x->h_qsize[k], sizeof(uint32_t) * x->h.qslots, hipMemcpyHostToDevice, x->stream) != hipSuccess) return CSCMI_DEVICE_ERROR;
+        if (hipMemcpyAsync(&x->d_state->avail[0], x->avail, sizeof(x->avail), hipMemcpyHostToDevice, x->stream) != hipSuccess) return CSCMI_DEVICE_ERROR;
+        launch_decode_run(x->d_state, x->stream);
+        if (hipGetLastError() != hipSuccess) return CSCMI_DEVICE_ERROR;
+        if (hipMemcpyAsync(x->h_read, x->d_state, sizeof(DecState), hipMemcpyDeviceToHost, x->stream) != hipSuccess) return CSCMI_DEVICE_ERROR;
+        if (hipStreamSynchronize(x->stream) != hipSuccess) return CSCMI_DEVICE_ERROR;
+        const DecState &r = *x->h_read;
+        x->taken[0] = r.taken[0]; x->taken[1] = r.taken[1];
+        x->consumed_view = r.consumed + r.rd[0] + r.rd[1];
+        switch (r.status) {
+        case DEC_DONE:
+            *size = r.out_size;
+            return 0;
+        case DEC_NEED_RC:
+        case DEC_NEED_BC:
+            if (read_block(x, r.status == DEC_NEED_RC ? 1 : 0) < 0)
+                return r.phase == DEC_PH_PRIME ? -1 : READ_ERROR;     // csc_dec.cpp:669-671 vs :17-18
+            break;
+        case DEC_ERR_MINUS1: return -1;
+        default: return DECODE_ERROR;
+        }
+    }
+}
+
+template <typename T>
+bool dalloc(T **p, size_t bytes)
+{
+    if (hipMalloc((void **)p, bytes) != hipSuccess) { *p = nullptr; return false; }
+    return hipMemset(*p, 0, bytes) == hipSuccess;
+}
+
+}  // namespace
+
+extern "C" {
+
+void CSCDec_ReadProperties(CSCProps *props, uint8_t *s)   // csc_dec.cpp:733-738
+{
+    props->dict_size = ((uint32_t)s[0] << 24) + ((uint32_t)s[1] << 16) + ((uint32_t)s[2] << 8) + s[3];
+    props->csc_blocksize = ((uint32_t)s[4] << 16) + ((uint32_t)s[5] << 8) + s[6];
+    props->raw_blocksize = ((uint32_t)s[7] << 16) + ((uint32_t)s[8] << 8) + s[9];
+}
+
+CSCDecHandle CSCDec_Create(const CSCProps *props, ISeqInStream *instream, ISzAlloc *alloc)   // csc_dec.cpp:692-720
+{
+    if (alloc == NULL) alloc = &g_default_alloc;
+    if (props->dict_size > 1024 * kMB || props->dict_size < 32 * kKB) return NULL;
+    if (props->csc_blocksize == 0 || props->raw_blocksize == 0) return NULL;
+    if (CSCMI_DeviceCheck() != 0) return NULL;
+    DecInstance *x = (DecInstance *)alloc->Alloc(alloc, sizeof(DecInstance));
+    if (!x) return NULL;
+    memset(x, 0, sizeof(*x));
+    x->magic = kMagicDec; x->alloc = alloc; x->is = instream;
+    DecState &h = x->h;
+    h.wnd_size = (uint32_t)props->dict_size; h.bsize = props->csc_blocksize; h.raw_blocksize = props->raw_blocksize;
+    h.qslots = 2 * (props->raw_blocksize / props->csc_blocksize + 1) + 16;
+    bool ok = hipGetDevice(&x->device) == hipSuccess && hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && dalloc(&h.wnd, (size_t)h.wnd_size + 256);
+    ok = ok && dalloc(&h.p_lit, 2 * 65536 * sizeof(uint32_t));
+    ok = ok && dalloc(&h.out, (size_t)h.raw_blocksize + 256) && dalloc(&h.swap, 2 * (size_t)h.raw_blocksize + 256);
+    ok = ok && dalloc(&h.q[0], (size_t)h.qslots * h.bsize + 64) && dalloc(&h.q[1], (size_t)h.qslots * h.bsize + 64);
+    ok = ok && dalloc(&h.qsize[0], sizeof(uint32_t) * h.qslots) && dalloc(&h.qsize[1], sizeof(uint32_t) * h.qslots);
+    ok = ok && dalloc(&h.undo_addr, sizeof(uint32_t) * kDecUndoCap) && dalloc(&h.undo_val, sizeof(uint32_t) * kDecUndoCap);
+    uint8_t *dwords = nullptr;
+    ok = ok && dalloc(&dwords, sizeof(kWords)) && hipMemcpy(dwords, kWords, sizeof(kWords), hipMemcpyHostToDevice) == hipSuccess;
+    h.words = dwords;
+    ok = ok && dalloc(&x->d_state, sizeof(DecState));
+    ok = ok && hipHostMalloc((void **)&x->h_read, sizeof(DecState), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&x->h_block, h.bsize, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&x->h_out, h.raw_blocksize, hipHostMallocDefault) == hipSuccess;
+    x->h_qsize[0] = (uint32_t *)calloc(h.qslots, sizeof(uint32_t));
+    x->h_qsize[1] = (uint32_t *)calloc(h.qslots, sizeof(uint32_t));
+    ok = ok && x->h_qsize[0] && x->h_qsize[1];
+    if (ok) {
+        h.p_delta = h.p_lit + 65536;
+        h.phase = DEC_PH_PRIME0;
+        ok = hipMemcpy(x->d_state, &h, sizeof(DecState), hipMemcpyHostToDevice) == hipSuccess;
+        if (ok) {
+            launch_decode_init(x->d_state, x->stream);
+            ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(x->stream) == hipSuccess;
+        }
+    }
+    // CSCDecoder::Init already reads the first RC and BC block (csc_dec.cpp:336-337)
+    if (!ok || read_block(x, 1) < 0 || read_block(x, 0) < 0) {
+        if (!ok) fprintf(stderr, "csc-mi355x: decoder device allocation failed\n");
+        free_all(x);
+        return NULL;
+    }
+    return (CSCDecHandle)x;
+}
+
+void CSCDec_Destroy(CSCDecHandle p)   // csc_dec.cpp:722-731
+{
+    DecInstance *x = (DecInstance *)p;
+    if (x && x->magic == kMagicDec) free_all(x);
+}
+
+int CSCDec_Decode(CSCDecHandle p, ISeqOutStream *os, ICompressProgress *progress)   // csc_dec.cpp:740-777
+{
+    DecInstance *x = (DecInstance *)p;
+    if (hipSetDevice(x->device) != hipSuccess) return CSCMI_DEVICE_ERROR;
+    int ret = 0;
+    uint64_t outsize = 0;
+    for (;;) {
+        uint32_t size = 0;
+        ret = decompress(x, &size);
+        if (ret == 0) outsize += size;
+        if (progress) progress->Progress(progress, x->consumed_view, outsize);
+        if (size == 0 || ret < 0) break;
+        if (hipMemcpy(x->h_out, x->h.out, size, hipMemcpyDeviceToHost) != hipSuccess) { ret = CSCMI_DEVICE_ERROR; break; }
+        size_t wrote = os->Write(os, x->h_out, size);
+        if (wrote == CSC_WRITE_ABORT) break;
+        if (wrote < size) { ret = WRITE_ERROR; break; }
+    }
+    return ret;
+}
+
+}  // extern "C"

@@ -113,4 +113,32 @@ struct EncState {
     uint32_t pf_sink[64];      // keeps the cache-warming loads of k_encode_runs alive
 };
 
+// ---------------------------------------------------------------------------------------------
+// decoder (csc_dec_kernels.hip / csc_dec_device.cpp)
+constexpr uint32_t kDecUndoCap = 32768;   // probability updates journalled per packet (RLE run lengths can take ~14.6 K long-length bits)
+enum : uint32_t { DEC_RUNNING = 0, DEC_DONE = 1, DEC_NEED_RC = 2, DEC_NEED_BC = 3, DEC_ERR_DECODE = 4, DEC_ERR_MINUS1 = 5 };
+enum : uint32_t { DEC_PH_PRIME0 = 0, DEC_PH_TYPE, DEC_PH_SIZE, DEC_PH_LZ, DEC_PH_RAW, DEC_PH_POST, DEC_PH_TAIL, DEC_PH_PRIME };
+
+struct DecState {
+    // configuration
+    uint32_t wnd_size, bsize, raw_blocksize, qslots;
+    uint8_t *wnd;              // dict_size + slack
+    uint32_t *p_lit, *p_delta; // ONE allocation of 2 x 64 Ki words: p_delta = p_lit + 65536
+    uint8_t *out, *swap;       // decoded run (raw_blocksize + slack), filter scratch
+    uint8_t *q[2];             // [1] RC / [0] BC block rings: qslots x bsize bytes
+    uint32_t *qsize[2];        // payload size per ring slot
+    uint32_t *undo_addr, *undo_val;
+    const uint8_t *words;      // 122 x 8 bytes: the dictionary filter's word list
+    // written by the host before every launch
+    uint32_t avail[2];         // blocks uploaded so far per kind
+    // stream state carried between launches
+    uint32_t taken[2], rd[2], fill[2];
+    uint32_t range, code, bc_bits, bc_val;
+    uint32_t state, ctx, rep[4], wnd_pos, p_delta_ready;
+    uint32_t phase, type, run_size, i, copied, copied_from;
+    uint32_t status, out_size;
+    uint64_t consumed;
+    uint32_t probs[P_COUNT + 4];
+};
+
 }  // namespace cscmi

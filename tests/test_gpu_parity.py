@@ -201,3 +201,63 @@ def test_batch_of_streams_equals_one_by_one(prod):
         L.CSCEnc_Destroy(h)
     for d, w in zip(datas, ws):
         assert bytes(w.out) == prod.encode(d, 3, len(d))[1]
+
+
+# ---- decode path (k_decode_run through CSCDec_*) ----
+@pytest.mark.parametrize("name,level", [("mix_types", 3), ("text_300k", 2), ("exe_300k", 5), ("delta_200k", 1),
+                                        ("window_wrap_32k", 3), ("periodic_5000x200", 4), ("empty", 3), ("one_byte", 5)])
+def test_device_decoder_on_oracle_streams(prod, orc, zalloc, name, level):
+    spec, dict_size, clamp, max_read = cases.STREAM_CASES[name]
+    data = cases.build(spec)
+    rc, s = orc.encode(data, level, dict_size, alloc=zalloc, clamp_dict=clamp, max_read=max_read)
+    assert rc == 0
+    assert prod.decode(s) == (0, data)
+    assert prod.decode(s, alloc=zalloc) == (0, data)                    # custom ISzAlloc
+    # MemIO::ReadBlock issues ONE Read per payload and rejects a short one (csc_memio.cpp:47-50): same here
+    assert prod.decode(s, max_read=1000) == orc.decode(s, alloc=zalloc, max_read=1000)
+
+
+def test_decoder_error_paths(prod, orc, zalloc):
+    from csc_amd.capi import BytesWriter
+    data = cases.build(cases.STREAM_CASES["mix_types"][0])
+    s = orc.encode(data, 3, 1 << 20, alloc=zalloc)[1]
+    rc, out = prod.decode(s, writer=BytesWriter(fail_after=100000))
+    assert rc == -97
+    rc, out = prod.decode(s, writer=BytesWriter(abort_after=100000))       # CSC_WRITE_ABORT ends silently (csc_dec.cpp:768)
+    assert rc == 0 and len(out) < len(data)
+    assert prod.decode(s[:10] + b"\x00" * 50)[0] is None                    # garbage after the header: Create fails
+    bad = bytearray(s); bad[0] = 0x7F                                       # dict_size > 1 GiB
+    assert prod.decode(bytes(bad))[0] is None
+    for cut in (len(s) - 3, len(s) // 2):
+        assert prod.decode(s[:cut]) == orc.decode(s[:cut], alloc=zalloc)
+
+
+
+
+@pytest.mark.timeout(600)
+def test_device_decoder_on_corrupted_streams(prod, orc, zalloc):
+    """bit flips and truncation: same return code and same bytes delivered as the oracle (= reference, see
+    tests/test_oracle_vs_ref.py::test_corrupted_streams_agree); never a fault or a hang"""
+    import random
+    data = cases.build(cases.STREAM_CASES["mix_types"][0])
+    s = orc.encode(data, 3, 1 << 20, alloc=zalloc)[1]
+    rnd = random.Random(11)
+    for _ in range(16):
+        b = bytearray(s)
+        k = rnd.randrange(40, len(b))
+        b[k] ^= 1 << rnd.randrange(8)
+        want = orc.decode(bytes(b), alloc=zalloc)
+        got = prod.decode(bytes(b))
+        assert got[0] == want[0] and got[1] == want[1], k
+    for cut in (len(s) - 3, len(s) // 2, 70000):
+        assert prod.decode(s[:cut]) == orc.decode(s[:cut], alloc=zalloc)
+
+
+def test_golden_streams_decode_on_device(prod, orc, zalloc):
+    """every reference vector small enough to carry its bytes: decode(stream_hex) == input"""
+    for key, want in STREAMS.items():
+        if "stream_hex" not in want:
+            continue
+        name = key.split("/m")[0]
+        data = cases.build(cases.STREAM_CASES[name][0])
+        assert prod.decode(bytes.fromhex(want["stream_hex"])) == (0, data), key
