@@ -174,7 +174,7 @@ CSCDecHandle CSCDec_Create(const CSCProps *props, ISeqInStream *instream, ISzAll
     ok = ok && dalloc(&h.wnd, (size_t)h.wnd_size + 256);
     ok = ok && dalloc(&h.p_lit, 2 * 65536 * sizeof(uint32_t));
     ok = ok && dalloc(&h.out, (size_t)h.raw_blocksize + 256) && dalloc(&h.swap, 2 * (size_t)h.raw_blocksize + 256);
-    ok = ok && dalloc(&h.q[0], (size_t)h.qslots * h.bsize + 64) && dalloc(&h.q[1], (size_t)h.qslots * h.bsize + 64);
+    ok = ok && dalloc(&h.q[0], (size_t)h.qslots * h.bsize + 256) && dalloc(&h.q[1], (size_t)h.qslots * h.bsize + 256);
     ok = ok && dalloc(&h.qsize[0], sizeof(uint32_t) * h.qslots) && dalloc(&h.qsize[1], sizeof(uint32_t) * h.qslots);
     ok = ok && dalloc(&h.undo_addr, sizeof(uint32_t) * kDecUndoCap) && dalloc(&h.undo_val, sizeof(uint32_t) * kDecUndoCap);
     uint8_t *dwords = nullptr;

@@ -40,6 +40,7 @@ struct Dc {
     uint32_t need;      // 0, or DEC_NEED_RC / DEC_NEED_BC once a block ran out with no successor uploaded
     uint32_t err;       // DECODE_ERROR-class failure inside a packet
     uint32_t undo_n;
+    uint32_t bv[2], bbase[2], btag[2];   // 64 bytes of the current RC / BC block, one per lane: block bytes [bbase, bbase+64) of block #btag
     // resume variables of the Decompress call in flight (mirrors of DecState fields)
     uint32_t phase, type, run_size, i, copied, copied_from, status, out_size, p_delta_ready;
 };
@@ -70,7 +71,7 @@ DDEV void ck_rollback(Dc &c, const Ck &k)
         else c.L->P[a] = v;
     }
     c.undo_n = 0;
-    for (int i = 0; i < 2; i++) { c.taken[i] = k.taken[i]; c.rd[i] = k.rd[i]; c.fill[i] = k.fill[i]; }
+    for (int i = 0; i < 2; i++) { c.taken[i] = k.taken[i]; c.rd[i] = k.rd[i]; c.fill[i] = k.fill[i]; c.btag[i] = 0xFFFFFFFFu; }
     c.range = k.range; c.code = k.code; c.bc_bits = k.bc_bits; c.bc_val = k.bc_val;
     c.state = k.state; c.ctx = k.ctx; c.wnd_pos = k.wnd_pos; c.consumed = k.consumed;
     for (int i = 0; i < 4; i++) c.rep[i] = k.rep[i];
@@ -81,8 +82,16 @@ DDEV void ck_rollback(Dc &c, const Ck &k)
 DDEV uint32_t next_byte(Dc &c, int kind)
 {
     if (c.need) return 0;
-    uint32_t slot = (c.taken[kind] - 1) % c.qslots;
-    uint32_t b = DUNI((uint32_t)c.q[kind][(size_t)slot * c.bsize + c.rd[kind]]);
+    // bytes are served from a 64-byte register window over the current block (one HBM fetch per 64 bytes)
+    uint32_t off = c.rd[kind] - c.bbase[kind];
+    if (c.btag[kind] != c.taken[kind] || off >= 64) {
+        uint32_t slot = (c.taken[kind] - 1) % c.qslots;
+        c.bbase[kind] = c.rd[kind];
+        c.btag[kind] = c.taken[kind];
+        c.bv[kind] = c.q[kind][(size_t)slot * c.bsize + c.rd[kind] + c.lane];   // ring has 64 bytes of slack
+        off = 0;
+    }
+    uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)c.bv[kind], (int)off);
     c.rd[kind]++;
     if (c.rd[kind] >= c.fill[kind]) {
         if (c.taken[kind] < c.avail[kind]) {
@@ -99,10 +108,9 @@ DDEV uint32_t next_byte(Dc &c, int kind)
 }
 
 // DecodeBit (csc_dec.cpp:10-35): space 0 = small tables in LDS, 1 = p_lit / p_delta words in HBM
-DDEV uint32_t dbit(Dc &c, uint32_t v, uint32_t space, uint32_t idx)
+DDEV uint32_t dbit_p(Dc &c, uint32_t v, uint32_t space, uint32_t idx, uint32_t p)
 {
     if (c.range < (1u << 24)) { c.range <<= 8; c.code = (c.code << 8) + next_byte(c, 1); }
-    uint32_t p = space ? DUNI(c.p_lit[idx]) : DUNI(c.L->P[idx]);
     uint32_t bound = (c.range >> 12) * p, np, bit;
     if (c.code < bound) { c.range = bound; np = p + ((0xFFFu - p) >> 5); bit = 1; }
     else { c.range -= bound; c.code -= bound; np = p - (p >> 5); bit = 0; }
@@ -117,6 +125,11 @@ DDEV uint32_t dbit(Dc &c, uint32_t v, uint32_t space, uint32_t idx)
         if (space) c.p_lit[idx] = np; else c.L->P[idx] = np;
     }
     return v + v + bit;
+}
+DDEV uint32_t dbit(Dc &c, uint32_t v, uint32_t space, uint32_t idx)
+{
+    uint32_t p = space ? DUNI(c.p_lit[idx]) : DUNI(c.L->P[idx]);
+    return dbit_p(c, v, space, idx, p);
 }
 
 DDEV uint32_t ddirect16(Dc &c, uint32_t len)   // coder_decode_direct, csc_dec.cpp:65-88
@@ -134,10 +147,27 @@ DDEV uint32_t dget_int(Dc &c)                  // decode_int, csc_dec.cpp:90-97
     uint32_t num = ddirect(c, slot == 0 ? 1 : slot);
     return slot ? num + (1u << slot) : num;
 }
-DDEV uint32_t dbyte_tree(Dc &c, uint32_t row_word)   // 8 bits under an order-1 row of p_lit / p_delta
+// 8 bits under an order-1 row of p_lit / p_delta.  The node of bit k depends on the bits before it,
+// so instead of 8 dependent HBM fetches the 15 nodes of the top 4 levels are fetched at once (heap
+// order: lane L = node L), then the 15 nodes of the 4-level subtree under the node reached.
+DDEV uint32_t dbyte_tree(Dc &c, uint32_t row_word)
 {
+    const uint32_t L = c.lane & 15;
+    uint32_t pv = c.p_lit[row_word + L];
     uint32_t v = 1;
-    do { v = dbit(c, v, 1, row_word + v); } while (v < 0x100);
+#pragma unroll
+    for (int k = 0; k < 4; k++) v = dbit_p(c, v, 1, row_word + v, (uint32_t)__builtin_amdgcn_readlane((int)pv, (int)v));
+    // subtree under node v (16..31): lane L = 2^j + t  ->  node (v << j) + t
+    const uint32_t j = 31u - (uint32_t)__builtin_clz(L | 1u);
+    uint32_t pv2 = c.p_lit[row_word + (v << j) + (L - (1u << j))];
+    uint32_t h = 1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)pv2, (int)h);
+        uint32_t nv = dbit_p(c, v, 1, row_word + v, p);
+        h = h + h + (nv & 1);
+        v = nv;
+    }
     return v & 0xFF;
 }
 DDEV uint32_t dmatchlen_1(Dc &c)               // csc_dec.cpp:187-220
@@ -404,6 +434,7 @@ __global__ __launch_bounds__(64) void k_decode_run(DecState *D)
     c.state = D->state; c.ctx = D->ctx; c.wnd_pos = D->wnd_pos; c.consumed = D->consumed;
     for (int i = 0; i < 4; i++) c.rep[i] = D->rep[i];
     c.need = 0; c.err = 0; c.undo_n = 0;
+    c.bv[0] = c.bv[1] = 0; c.bbase[0] = c.bbase[1] = 0; c.btag[0] = c.btag[1] = 0xFFFFFFFFu;
     c.phase = D->phase; c.type = D->type; c.run_size = D->run_size; c.i = D->i; c.copied = D->copied; c.copied_from = D->copied_from;
     c.out_size = D->out_size; c.p_delta_ready = D->p_delta_ready; c.status = DEC_RUNNING;
     for (uint32_t i = c.lane; i < P_COUNT; i += 64) lds.P[i] = D->probs[i];
