@@ -1,0 +1,113 @@
+/*
+ * csa_mi355x.h -- C ABI of the `.csa` container layer of libcsc_mi355x.so.
+ *
+ * The reference's archiver (src/archiver) is a command-line program, not a library: its interface
+ * is the four operations of `class CSArc` (csarc.cpp:37-70) and their options (ParseArg,
+ * csarc.cpp:137-208).  This header gives each of them a C entry point with the same meaning, the
+ * same return value and -- for `CSA_Add` -- the same bytes on disk as `csarc a -t1`:
+ *
+ *   reference                                    here
+ *   CSArc::Add      csarc.cpp:472-575            CSA_Add
+ *   CSArc::Extract  csarc.cpp:600-650            CSA_Extract
+ *   CSArc::Test     csarc.cpp:667-700            CSA_Test
+ *   CSArc::List     csarc.cpp:652-665            CSA_List
+ *   adler32()       csa_adler32.cpp:63-129       CSA_Adler32 (host), CSAMI_Adler32Device (HIP kernel)
+ *   PackIndex / UnpackIndex csa_indexpack.cpp:166-211   inside CSA_Add / the readers; CSA_ReadIndex exposes the raw bytes
+ *
+ * What runs where: the task streams and the index stream are libcsc streams produced by the HIP
+ * encoder behind CSCEnc_* (many task streams advance together, one workgroup per stream); the
+ * per-fragment adler32 is a HIP reduction over the chunk that is already in HBM for the encoder;
+ * decoding uses the HIP decoder behind CSCDec_*.  Directory scan, task split, block table, index
+ * packing and file I/O are host code, as in the reference.  No CPU codec exists in this library.
+ */
+#ifndef CSA_MI355X_H_
+#define CSA_MI355X_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Options of `csarc` (ParseArg, csarc.cpp:137-208).  CSA_OptionsInit sets the reference defaults. */
+typedef struct CSAOptions {
+    int level;              /* -m#      1..5, default 2                         csarc.cpp:141,150-156 */
+    uint32_t dict_size;     /* -d##[k|m] 32 KiB..1 GiB, default 32000000        csarc.cpp:140,157-168 */
+    int recurse;            /* -r                                               csarc.cpp:169-170 */
+    int overwrite;          /* -f                                               csarc.cpp:171-172 */
+    int verbose;            /* -v (List: report fragments)                      csarc.cpp:173-174 */
+    int mt_count;           /* -t#  Extract/Test: concurrent task decoders (1..64 here; the reference
+                               clamps to 8).  Add: ignored -- the archive is always laid out as the
+                               reference's single-worker run lays it out (task-id order).          */
+    int split_count;        /* -p##  single-file split, default 1               csarc.cpp:190-191 */
+    const char *to_dir;     /* -o dir, default "./"                             csarc.cpp:147,183-189 */
+    /* --- not in the reference --- */
+    int device_streams;     /* Add: how many task streams advance per kernel launch; 0 = as many as
+                               fit the HBM budget (at most 1024)                                     */
+    uint64_t hbm_budget;    /* Add: bytes of HBM the concurrent task encoders may use; 0 = 3/4 of
+                               the free device memory                                                */
+} CSAOptions;
+
+typedef struct CSAStats {
+    uint64_t raw_bytes;              /* bytes read from the input files */
+    uint64_t archive_bytes;          /* final size of the archive */
+    uint64_t index_raw_size;
+    uint64_t index_compressed_size;
+    uint32_t n_entries;              /* index entries (files and directories) */
+    uint32_t n_tasks;
+    uint32_t n_blocks;               /* archive blocks of all tasks */
+    uint32_t verify_failures;        /* Extract/Test: fragments whose adler32 did not match */
+    double seconds_total;
+    double seconds_encode;           /* Add: inside the batched encoder calls; Extract/Test: decode wall time */
+    uint32_t peak_streams;           /* Add: most task streams in flight at once */
+    uint32_t reserved;
+} CSAStats;
+
+typedef struct CSAFrag {             /* FileEntry::Frag, csa_typedef.h:18-24 */
+    uint32_t bid;                    /* task (archive-blocks) id */
+    uint32_t checksum;               /* adler32, seed 0 */
+    uint64_t posblock;               /* offset inside the task's raw stream */
+    uint64_t size;
+    uint64_t posfile;                /* offset inside the file */
+} CSAFrag;
+
+/* One call per index entry in name order (what `csarc l` prints, csarc.cpp:656-663). */
+typedef void (*CSAListFn)(void *ctx, const char *name, int64_t esize, int64_t edate, int64_t eattr,
+                          int nfrags, const CSAFrag *frags);
+
+void CSA_OptionsInit(CSAOptions *o);
+
+/* `csarc a [opts] arcname filenames...`.  Returns 0; 1 if the archive exists and !overwrite
+ * (csarc.cpp:474-483); CSCMI_DEVICE_ERROR / READ_ERROR / WRITE_ERROR style negatives when the
+ * encoder or the file system fails (the reference ignores those). */
+int CSA_Add(const char *arcname, const char *const *filenames, int nfilenames, const CSAOptions *o, CSAStats *st);
+
+/* `csarc x`: 0 ok, 1 bad header (csarc.cpp:602-603), -1 decode error (csarc.cpp:464-468).
+ * A failed adler32 is reported on stderr like the reference does and counted in st->verify_failures;
+ * it does not change the return value (csa_io.h:331-332). */
+int CSA_Extract(const char *arcname, const char *const *filenames, int nfilenames, const CSAOptions *o, CSAStats *st);
+
+/* `csarc t`: 0 ok, -1 bad header or decode error (csarc.cpp:669-670,697-700). */
+int CSA_Test(const char *arcname, const char *const *filenames, int nfilenames, const CSAOptions *o, CSAStats *st);
+
+/* `csarc l`: 0 ok, -1 bad header (csarc.cpp:654-655). */
+int CSA_List(const char *arcname, const char *const *filenames, int nfilenames, CSAListFn fn, void *ctx);
+
+/* The raw (unpacked) index bytes of an archive, for tools and tests: returns the raw size, or -1.
+ * Copies at most cap bytes into buf (buf may be NULL to query the size). */
+int64_t CSA_ReadIndex(const char *arcname, uint8_t *buf, uint64_t cap);
+
+/* adler32 of csa_adler32.cpp:63-129 (zlib's, with the running value passed in; the archiver seeds
+ * fragments with 0).  Host version, and the HIP reduction over a device buffer. */
+uint32_t CSA_Adler32(uint32_t adler, const uint8_t *buf, uint64_t len);
+int CSAMI_Adler32Device(uint32_t adler, const void *device_ptr, uint64_t len, uint32_t *out);
+
+/* YYYYMMDDHHMMSS <-> time_t, csa_common.cpp:3-39 */
+int64_t CSA_DecimalTime(int64_t unix_seconds);
+int64_t CSA_UnixTime(int64_t decimal_date);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSA_MI355X_H_ */
