@@ -24,6 +24,7 @@ class CSAStats(C.Structure):
         ("index_compressed_size", C.c_uint64), ("n_entries", C.c_uint32), ("n_tasks", C.c_uint32),
         ("n_blocks", C.c_uint32), ("verify_failures", C.c_uint32), ("seconds_total", C.c_double),
         ("seconds_encode", C.c_double), ("peak_streams", C.c_uint32), ("reserved", C.c_uint32),
+        ("seconds_io", C.c_double), ("seconds_setup", C.c_double),
     ]
 
     def as_dict(self):

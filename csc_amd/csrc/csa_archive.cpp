@@ -556,6 +556,7 @@ int encode_tasks(std::vector<Task> &tasks, BlockIndex &abindex, int arc_fd, uint
 
     while (rc == 0) {
         // ---- admit tasks into free slots, in task-id order (largest first, csarc.cpp:355)
+        double ts = now_s();
         while (next_admit < nt) {
             CSCProps p;
             CSCEncProps_Init(&p, (uint32_t)std::min<uint64_t>(o.dict_size, tasks[next_admit].total), o.level);   // csa_worker.cpp:35
@@ -579,8 +580,10 @@ int encode_tasks(std::vector<Task> &tasks, BlockIndex &abindex, int arc_fd, uint
             if (st) st->peak_streams = std::max<uint32_t>(st->peak_streams, (uint32_t)active + 1);
         }
         if (rc) break;
+        if (st) st->seconds_setup += now_s() - ts;
 
         // ---- one chunk per live stream: read, upload, adler32
+        ts = now_s();
         hs.clear(); ptrs.clear(); sizes.clear(); live.clear();
         for (size_t i = 0; i < slots.size(); i++) {
             Slot &s = slots[i];
@@ -594,6 +597,7 @@ int encode_tasks(std::vector<Task> &tasks, BlockIndex &abindex, int arc_fd, uint
         if (live.empty()) break;
         rc = run_adler(J, slots);                                           // also waits for the uploads
         if (rc) break;
+        if (st) st->seconds_io += now_s() - ts;
 
         // ---- advance every stream by its chunk with one launch per parser flavour
         if (!hs.empty()) {
@@ -604,6 +608,7 @@ int encode_tasks(std::vector<Task> &tasks, BlockIndex &abindex, int arc_fd, uint
         }
 
         // ---- streams whose task has no bytes left: EOF, flush, hand the blocks to the writer
+        ts = now_s();
         for (uint32_t i : live) {
             Slot &s = slots[i];
             Task &t = tasks[s.task];
@@ -619,6 +624,7 @@ int encode_tasks(std::vector<Task> &tasks, BlockIndex &abindex, int arc_fd, uint
             s.task = -1;
         }
         if (rc) break;
+        if (st) st->seconds_setup += now_s() - ts;
         rc = flush_written();
     }
     if (rc == 0) rc = flush_written();

@@ -37,7 +37,6 @@ using namespace cscmi;
 
 namespace {
 
-const uint32_t kDltIndexHost[5] = {1, 2, 3, 4, 8};   // csc_typedef.h:36
 constexpr uint32_t kMagicEnc = 0x43534345;           // "CSCE"
 constexpr int kEventPairs = 32;
 
@@ -88,6 +87,117 @@ void build_trie(uint16_t *next, uint8_t *sym)
 std::once_flag g_tables_once;
 hipError_t g_tables_err = hipSuccess;
 
+// Per-handle resources that do not depend on the stream's content are recycled: creating a handle
+// costs a pinned allocation, a stream and ~70 events otherwise, and an archive job creates one handle
+// per task (hundreds).  HostRes = pinned staging slab + HIP stream + events, keyed by (device, size);
+// DevSlab = the ONE device allocation all of a handle's HBM state is carved from, keyed by
+// (device, size) and zero-filled again on every reuse (the reference's determinism condition).
+struct HostRes {
+    int device;
+    size_t hsize;
+    uint8_t *hslab;
+    uint8_t *h_in;              // lazily allocated: only CSCEnc_Encode / CSCMI_EncodeHostChunk stage input on the host
+    hipStream_t stream;
+    hipEvent_t ev[32][2];
+    hipEvent_t ev_an[2];
+};
+struct DevSlab { int device; size_t size; void *p; };
+
+std::mutex g_cache_mu;
+std::vector<HostRes *> g_host_cache;
+std::vector<DevSlab> g_dev_cache;
+size_t g_dev_cache_bytes = 0;
+constexpr size_t kHostCacheMax = 1280;            // entries (~7 MiB pinned each)
+constexpr size_t kDevCacheMaxBytes = 48ull << 30;
+
+void host_res_destroy(HostRes *r)
+{
+    if (!r) return;
+    if (r->hslab) (void)hipHostFree(r->hslab);
+    if (r->h_in) (void)hipHostFree(r->h_in);
+    for (auto &pr : r->ev) for (auto &e : pr) if (e) (void)hipEventDestroy(e);
+    for (auto &e : r->ev_an) if (e) (void)hipEventDestroy(e);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+}
+
+HostRes *host_res_get(int device, size_t hsize)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (size_t i = 0; i < g_host_cache.size(); i++)
+            if (g_host_cache[i]->device == device && g_host_cache[i]->hsize == hsize) {
+                HostRes *r = g_host_cache[i];
+                g_host_cache.erase(g_host_cache.begin() + i);
+                return r;
+            }
+    }
+    HostRes *r = new HostRes();
+    memset(r, 0, sizeof(*r));
+    r->device = device; r->hsize = hsize;
+    bool ok = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&r->hslab, hsize, hipHostMallocDefault) == hipSuccess;
+    for (auto &pr : r->ev) for (auto &e : pr) ok = ok && hipEventCreate(&e) == hipSuccess;
+    for (auto &e : r->ev_an) ok = ok && hipEventCreate(&e) == hipSuccess;
+    if (!ok) { host_res_destroy(r); return nullptr; }
+    return r;
+}
+
+void host_res_put(HostRes *r)
+{
+    if (!r) return;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        if (g_host_cache.size() < kHostCacheMax) { g_host_cache.push_back(r); return; }
+    }
+    host_res_destroy(r);
+}
+
+void dev_cache_trim()
+{
+    std::vector<DevSlab> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        drop.swap(g_dev_cache);
+        g_dev_cache_bytes = 0;
+    }
+    for (DevSlab &d : drop) (void)hipFree(d.p);
+}
+
+void *dev_slab_get(int device, size_t size)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (size_t i = 0; i < g_dev_cache.size(); i++)
+            if (g_dev_cache[i].device == device && g_dev_cache[i].size == size) {
+                void *p = g_dev_cache[i].p;
+                g_dev_cache.erase(g_dev_cache.begin() + i);
+                g_dev_cache_bytes -= size;
+                return p;
+            }
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, size) == hipSuccess) return p;
+    (void)hipGetLastError();
+    dev_cache_trim();                              // give the cached slabs back and try once more
+    if (hipMalloc(&p, size) == hipSuccess) return p;
+    return nullptr;
+}
+
+void dev_slab_put(int device, size_t size, void *p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        if (g_dev_cache_bytes + size <= kDevCacheMaxBytes) {
+            g_dev_cache.push_back(DevSlab{device, size, p});
+            g_dev_cache_bytes += size;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
 struct EncInstance {
     uint32_t magic;
     ISzAlloc *alloc;
@@ -100,6 +210,9 @@ struct EncInstance {
     RunDesc *d_runs;
     double *d_entcoef;
     uint8_t *d_trie;            // next (u16[7800]) + sym (u8[300])
+    void *dslab;                // everything above and in `h` is carved from this one allocation
+    size_t dsize;
+    HostRes *res;               // stream, events and the pinned slab the pointers below point into
     // pinned staging
     uint8_t *h_in;
     uint8_t *h_arena;
@@ -107,8 +220,8 @@ struct EncInstance {
     RunDesc *h_runs;
     uint32_t *h_dup;
     uint32_t *h_small;
-    hipEvent_t ev[kEventPairs][2];
-    hipEvent_t ev_an[2];
+    hipEvent_t (*ev)[2];        // res->ev
+    hipEvent_t *ev_an;          // res->ev_an
     // accounting
     int64_t outsize;            // GetCompressedSize, csc_encoder_main.cpp:174
     CSCMIStats stats;
@@ -117,31 +230,20 @@ struct EncInstance {
     uint32_t pend_a, pend_b;
     bool pend_first;
     int pend_ev;
-    void **d_batch;             // [3 * kMaxBatch] device arrays: states, run lists, run counts (as pointers-sized words)
-    void **h_batch;
 };
+// argument arrays of the multi-stream launch ([4 * kMaxBatch] pointer-sized words: states, run lists, run
+// counts, reset flags), one set per calling thread and device, kept for the life of the thread
+struct BatchArgs { int device = -1; void **d = nullptr; void **h = nullptr; };
+thread_local BatchArgs t_batch;
 constexpr int kMaxBatch = 2048;
 
 void free_device(EncInstance *e)
 {
-    hipSetDevice(e->device);
-    auto F = [](void *p) { if (p) hipFree(p); };
-    F(e->h.wnd); F(e->h.mfbuf); F(e->h.p_lit); F(e->h.p_delta); F(e->h.rc_buf); F(e->h.bc_buf);
-    F(e->h.inbuf); F(e->h.swapbuf); F(e->h.arena); F(e->h.binfo); F(e->h.dup_flags);
-    F(e->d_trie); F(e->d_runs); F(e->d_entcoef); F(e->d_state); F(e->d_batch);
-    auto H = [](void *p) { if (p) hipHostFree(p); };
-    H(e->h_in); H(e->h_arena); H(e->h_binfo); H(e->h_runs); H(e->h_dup); H(e->h_small); H(e->h_batch);
-    for (int i = 0; i < kEventPairs; i++) for (int j = 0; j < 2; j++) if (e->ev[i][j]) hipEventDestroy(e->ev[i][j]);
-    for (int j = 0; j < 2; j++) if (e->ev_an[j]) hipEventDestroy(e->ev_an[j]);
-    if (e->stream) hipStreamDestroy(e->stream);
-}
-
-template <typename T>
-hipError_t dmalloc_zero(T **p, size_t bytes, hipStream_t st)
-{
-    hipError_t err = hipMalloc((void **)p, bytes);
-    if (err != hipSuccess) { *p = nullptr; return err; }
-    return hipMemsetAsync(*p, 0, bytes, st);
+    (void)hipSetDevice(e->device);
+    if (e->res) (void)hipStreamSynchronize(e->res->stream);
+    dev_slab_put(e->device, e->dsize, e->dslab);
+    host_res_put(e->res);
+    e->dslab = nullptr; e->res = nullptr; e->stream = nullptr;
 }
 
 // MemIO::WriteBlock, csc_memio.cpp:83-108: flag byte, [3-byte BE size], payload -- 2-3 Write calls
@@ -408,7 +510,6 @@ CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *outstream, ISzA
     bool ok = hipGetDevice(&e->device) == hipSuccess;
     // each process/thread may sit on another device: the constant tables are per device
     if (ok) ok = upload_tables() == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
 
     EncState &h = e->h;
     // LZ::Init / MatchFinder::Init geometry, csc_lz.cpp:15-33, csc_mf.cpp:45-106
@@ -428,31 +529,41 @@ CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *outstream, ISzA
     if (h.bt_bits) h.mf_size += ((uint64_t)1 << h.bt_bits) + (uint64_t)h.bt_size * 2;
     h.arena_cap = 3 * props->raw_blocksize + kMB;
 
+    // ---- one device slab, zero-filled: memset(wnd_, 0, ..) csc_lz.cpp:50, the tables csc_mf.cpp:73, and the
+    // coder buffers, which the reference reads before writing (App. C #1)
+    size_t doff = 0;
+    auto dtake = [&](size_t bytes) { size_t o = doff; doff += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_wnd = dtake((size_t)wnd + 256), o_mf = dtake((h.mf_size + 64) * sizeof(uint32_t));
+    const size_t o_plit = dtake(256 * 256 * sizeof(uint32_t)), o_pdelta = dtake(256 * 256 * sizeof(uint32_t));
+    const size_t o_rc = dtake((size_t)h.bsize + 64), o_bc = dtake((size_t)h.bsize + 64);
+    const size_t o_in = dtake((size_t)h.raw_blocksize + 256), o_swap = dtake(4 * (size_t)h.raw_blocksize + 512);
+    const size_t o_arena = dtake((size_t)h.arena_cap + 64), o_binfo = dtake(sizeof(BlockInfo) * kMaxBlocksPerChunk);
+    const size_t o_dup = dtake(sizeof(uint32_t) * kMaxBlocksPerChunk), o_trie = dtake(300 * 26 * 2 + 320);
+    const size_t o_runs = dtake(sizeof(RunDesc) * (kMaxBlocksPerChunk + 2)), o_coef = dtake(sizeof(double) * 16);
+    const size_t o_state = dtake(sizeof(EncState));
+    e->dsize = doff;
+    // ---- one pinned slab
+    size_t hoff = 0;
+    auto htake = [&](size_t bytes) { size_t o = hoff; hoff += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t p_arena = htake((size_t)h.arena_cap + 64), p_binfo = htake(sizeof(BlockInfo) * kMaxBlocksPerChunk);
+    const size_t p_runs = htake(sizeof(RunDesc) * (kMaxBlocksPerChunk + 2)), p_dup = htake(sizeof(uint32_t) * kMaxBlocksPerChunk);
+    const size_t p_small = htake(64);
+
+    if (ok) { e->res = host_res_get(e->device, hoff); ok = e->res != nullptr; }
+    if (ok) { e->dslab = dev_slab_get(e->device, e->dsize); ok = e->dslab != nullptr; }
+    if (ok) {
+        e->stream = e->res->stream; e->ev = e->res->ev; e->ev_an = e->res->ev_an;
+        uint8_t *D = (uint8_t *)e->dslab, *H = e->res->hslab;
+        h.wnd = D + o_wnd; h.mfbuf = (uint32_t *)(D + o_mf); h.p_lit = (uint32_t *)(D + o_plit); h.p_delta = (uint32_t *)(D + o_pdelta);
+        h.rc_buf = D + o_rc; h.bc_buf = D + o_bc; h.inbuf = D + o_in; h.swapbuf = D + o_swap; h.arena = D + o_arena;
+        h.binfo = (BlockInfo *)(D + o_binfo); h.dup_flags = (uint32_t *)(D + o_dup); e->d_trie = D + o_trie;
+        e->d_runs = (RunDesc *)(D + o_runs); e->d_entcoef = (double *)(D + o_coef); e->d_state = (EncState *)(D + o_state);
+        e->h_in = e->res->h_in;
+        e->h_arena = H + p_arena; e->h_binfo = (BlockInfo *)(H + p_binfo); e->h_runs = (RunDesc *)(H + p_runs);
+        e->h_dup = (uint32_t *)(H + p_dup); e->h_small = (uint32_t *)(H + p_small);
+        ok = hipMemsetAsync(e->dslab, 0, e->dsize, e->stream) == hipSuccess;
+    }
     hipStream_t st = e->stream;
-    ok = ok && dmalloc_zero(&h.wnd, (size_t)wnd + 256, st) == hipSuccess;               // memset(wnd_, 0, ..), csc_lz.cpp:50
-    ok = ok && dmalloc_zero(&h.mfbuf, (h.mf_size + 64) * sizeof(uint32_t), st) == hipSuccess;   // csc_mf.cpp:73
-    ok = ok && dmalloc_zero(&h.p_lit, 256 * 256 * sizeof(uint32_t), st) == hipSuccess;
-    ok = ok && dmalloc_zero(&h.p_delta, 256 * 256 * sizeof(uint32_t), st) == hipSuccess;
-    ok = ok && dmalloc_zero(&h.rc_buf, (size_t)h.bsize + 64, st) == hipSuccess;         // persistent, zero once (App. C #1)
-    ok = ok && dmalloc_zero(&h.bc_buf, (size_t)h.bsize + 64, st) == hipSuccess;
-    ok = ok && dmalloc_zero(&h.inbuf, (size_t)h.raw_blocksize + 256, st) == hipSuccess;
-    ok = ok && dmalloc_zero(&h.swapbuf, 4 * (size_t)h.raw_blocksize + 512, st) == hipSuccess;
-    ok = ok && dmalloc_zero(&h.arena, (size_t)h.arena_cap + 64, st) == hipSuccess;
-    ok = ok && dmalloc_zero(&h.binfo, sizeof(BlockInfo) * kMaxBlocksPerChunk, st) == hipSuccess;
-    ok = ok && dmalloc_zero(&h.dup_flags, sizeof(uint32_t) * kMaxBlocksPerChunk, st) == hipSuccess;
-    ok = ok && dmalloc_zero(&e->d_trie, 300 * 26 * 2 + 320, st) == hipSuccess;
-    ok = ok && dmalloc_zero(&e->d_runs, sizeof(RunDesc) * (kMaxBlocksPerChunk + 2), st) == hipSuccess;
-    ok = ok && dmalloc_zero(&e->d_entcoef, sizeof(double) * 16, st) == hipSuccess;
-    ok = ok && dmalloc_zero(&e->d_state, sizeof(EncState), st) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&e->h_in, h.raw_blocksize, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&e->h_arena, (size_t)h.arena_cap + 64, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&e->h_binfo, sizeof(BlockInfo) * kMaxBlocksPerChunk, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&e->h_runs, sizeof(RunDesc) * (kMaxBlocksPerChunk + 2), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&e->h_dup, sizeof(uint32_t) * kMaxBlocksPerChunk, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&e->h_small, 64, hipHostMallocDefault) == hipSuccess;
-    for (int i = 0; ok && i < kEventPairs; i++)
-        for (int j = 0; j < 2; j++) ok = ok && hipEventCreate(&e->ev[i][j]) == hipSuccess;
-    for (int j = 0; ok && j < 2; j++) ok = ok && hipEventCreate(&e->ev_an[j]) == hipSuccess;
     if (!ok) {
         fprintf(stderr, "csc-mi355x: device allocation failed (%s)\n", hipGetErrorString(hipGetLastError()));
         free_device(e);
@@ -476,12 +587,12 @@ CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *outstream, ISzA
         for (int d = 6; d < 16; d++) coef[d - 6] = log((double)d - 2) / log((double)2) - 0.6;
         ok = hipMemcpyAsync(e->d_trie, trie.data(), trie.size(), hipMemcpyHostToDevice, st) == hipSuccess
           && hipMemcpyAsync(e->d_entcoef, coef, sizeof(coef), hipMemcpyHostToDevice, st) == hipSuccess
-          && hipMemcpyAsync(e->d_state, &h, sizeof(EncState), hipMemcpyHostToDevice, st) == hipSuccess
-          && hipStreamSynchronize(st) == hipSuccess;
-    }
-    if (ok) {
-        launch_init_state(e->d_state, st);
-        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess && g_tables_err == hipSuccess;
+          && hipMemcpyAsync(e->d_state, &h, sizeof(EncState), hipMemcpyHostToDevice, st) == hipSuccess;
+        if (ok) {
+            launch_init_state(e->d_state, st);
+            ok = hipGetLastError() == hipSuccess;
+        }
+        ok = ok && hipStreamSynchronize(st) == hipSuccess && g_tables_err == hipSuccess;   // the sources above are locals
     }
     if (!ok) {
         fprintf(stderr, "csc-mi355x: device initialisation failed (%s)\n", hipGetErrorString(hipGetLastError()));
@@ -520,10 +631,15 @@ int CSCMI_EncodeDeviceChunkBatch(int n, CSCEncHandle *hs, const void *const *dev
     if (n > kMaxBatch) return -1;
     EncInstance *lead = (EncInstance *)hs[0];
     HIPCHK(hipSetDevice(lead->device));
-    if (!lead->d_batch) {
-        HIPCHK(hipMalloc((void **)&lead->d_batch, sizeof(void *) * 4 * kMaxBatch));
-        HIPCHK(hipHostMalloc((void **)&lead->h_batch, sizeof(void *) * 4 * kMaxBatch, hipHostMallocDefault));
+    if (t_batch.device != lead->device) {
+        if (t_batch.d) (void)hipFree(t_batch.d);
+        if (t_batch.h) (void)hipHostFree(t_batch.h);
+        t_batch = BatchArgs();
+        HIPCHK(hipMalloc((void **)&t_batch.d, sizeof(void *) * 4 * kMaxBatch));
+        HIPCHK(hipHostMalloc((void **)&t_batch.h, sizeof(void *) * 4 * kMaxBatch, hipHostMallocDefault));
+        t_batch.device = lead->device;
     }
+    void **const d_batch = t_batch.d, **const h_batch = t_batch.h;
     int rc = 0;
     for (int i = 0; i < n && !rc; i++) rc = sizes[i] ? chunk_begin((EncInstance *)hs[i], device_ptrs[i], sizes[i], true) : 0;
     for (int i = 0; i < n && !rc; i++) rc = sizes[i] ? chunk_segment((EncInstance *)hs[i], sizes[i], true) : 0;
@@ -532,10 +648,10 @@ int CSCMI_EncodeDeviceChunkBatch(int n, CSCEncHandle *hs, const void *const *dev
     for (int parser = 2; parser <= 7; parser++) {
         if ((parser & 3) < 2) continue;
         uint32_t m = 0;
-        EncState **st = (EncState **)lead->h_batch;
-        const RunDesc **rl = (const RunDesc **)(lead->h_batch + kMaxBatch);
-        uint32_t *cnt = (uint32_t *)(lead->h_batch + 2 * kMaxBatch);
-        uint32_t *rst = (uint32_t *)(lead->h_batch + 3 * kMaxBatch);
+        EncState **st = (EncState **)h_batch;
+        const RunDesc **rl = (const RunDesc **)(h_batch + kMaxBatch);
+        uint32_t *cnt = (uint32_t *)(h_batch + 2 * kMaxBatch);
+        uint32_t *rst = (uint32_t *)(h_batch + 3 * kMaxBatch);
         for (int i = 0; i < n; i++) {
             EncInstance *e = (EncInstance *)hs[i];
             if (!sizes[i] || e->parser != parser || e->pend_a == e->pend_b) continue;
@@ -545,10 +661,10 @@ int CSCMI_EncodeDeviceChunkBatch(int n, CSCEncHandle *hs, const void *const *dev
             m++;
         }
         if (!m) continue;
-        HIPCHK(hipMemcpyAsync(lead->d_batch, lead->h_batch, sizeof(void *) * 4 * kMaxBatch, hipMemcpyHostToDevice, lead->stream));
+        HIPCHK(hipMemcpyAsync(d_batch, h_batch, sizeof(void *) * 4 * kMaxBatch, hipMemcpyHostToDevice, lead->stream));
         HIPCHK(hipEventRecord(lead->ev[0][0], lead->stream));
-        launch_encode_runs_multi(parser, m, (EncState *const *)lead->d_batch, (const RunDesc *const *)(lead->d_batch + kMaxBatch),
-                                 (const uint32_t *)(lead->d_batch + 2 * kMaxBatch), (const uint32_t *)(lead->d_batch + 3 * kMaxBatch), lead->stream);
+        launch_encode_runs_multi(parser, m, (EncState *const *)d_batch, (const RunDesc *const *)(d_batch + kMaxBatch),
+                                 (const uint32_t *)(d_batch + 2 * kMaxBatch), (const uint32_t *)(d_batch + 3 * kMaxBatch), lead->stream);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(lead->ev[0][1], lead->stream));
         HIPCHK(hipStreamSynchronize(lead->stream));
@@ -571,6 +687,11 @@ int CSCEnc_Encode(CSCEncHandle p, ISeqInStream *is, ICompressProgress *progress)
     EncInstance *e = (EncInstance *)p;
     int ret = 0;
     uint64_t insize = 0;
+    if (!e->h_in) {   // pinned staging for the caller's Read, kept with the recycled host resources
+        HIPCHK(hipSetDevice(e->device));
+        HIPCHK(hipHostMalloc((void **)&e->res->h_in, e->props.raw_blocksize, hipHostMallocDefault));
+        e->h_in = e->res->h_in;
+    }
     for (;;) {
         size_t size = e->props.raw_blocksize;
         ret = is->Read(is, e->h_in, &size);
@@ -602,7 +723,7 @@ void CSCMI_GetStats(CSCEncHandle p, CSCMIStats *out)
     EncInstance *e = (EncInstance *)p;
     KernelStats ks;
     memset(&ks, 0, sizeof(ks));
-    hipSetDevice(e->device);
+    (void)hipSetDevice(e->device);
     if (hipMemcpy(&ks, &e->d_state->stats, sizeof(ks), hipMemcpyDeviceToHost) == hipSuccess) {
         e->stats.find_match_calls = ks.find_match_calls; e->stats.slide_positions = ks.slide_positions;
         e->stats.bt_steps = ks.bt_steps; e->stats.literals = ks.literals; e->stats.matches = ks.matches;
@@ -616,7 +737,7 @@ void CSCMI_DebugTimers(CSCEncHandle p, uint64_t *out16)
     EncInstance *e = (EncInstance *)p;
     KernelStats ks;
     memset(&ks, 0, sizeof(ks));
-    hipSetDevice(e->device);
+    (void)hipSetDevice(e->device);
     (void)hipMemcpy(&ks, &e->d_state->stats, sizeof(ks), hipMemcpyDeviceToHost);
     for (int i = 0; i < 16; i++) out16[i] = ks.tm[i];
 }

@@ -62,6 +62,8 @@ typedef struct CSAStats {
     double seconds_encode;           /* Add: inside the batched encoder calls; Extract/Test: decode wall time */
     uint32_t peak_streams;           /* Add: most task streams in flight at once */
     uint32_t reserved;
+    double seconds_io;               /* Add: file reads + uploads + adler32 kernel (not overlapped with encoding) */
+    double seconds_setup;            /* Add: creating / flushing / destroying the task encoders */
 } CSAStats;
 
 typedef struct CSAFrag {             /* FileEntry::Frag, csa_typedef.h:18-24 */
