@@ -14,7 +14,7 @@ class CSAOptions(C.Structure):
     _fields_ = [
         ("level", C.c_int), ("dict_size", C.c_uint32), ("recurse", C.c_int), ("overwrite", C.c_int),
         ("verbose", C.c_int), ("mt_count", C.c_int), ("split_count", C.c_int), ("to_dir", C.c_char_p),
-        ("device_streams", C.c_int), ("hbm_budget", C.c_uint64),
+        ("device_streams", C.c_int), ("hbm_budget", C.c_uint64), ("task_bytes", C.c_uint64),
     ]
 
 
@@ -79,14 +79,14 @@ def _names(filenames: Iterable[str]):
 
 def options(level: int = 2, dict_size: int = 32000000, recurse: bool = False, overwrite: bool = False,
             verbose: bool = False, mt_count: int = 1, split_count: int = 1, to_dir: Optional[str] = None,
-            device_streams: int = 0, hbm_budget: int = 0) -> CSAOptions:
+            device_streams: int = 0, hbm_budget: int = 0, task_bytes: int = 0) -> CSAOptions:
     o = CSAOptions()
     lib().CSA_OptionsInit(C.byref(o))
     o.level, o.dict_size, o.recurse, o.overwrite = level, dict_size, int(recurse), int(overwrite)
     o.verbose, o.mt_count, o.split_count = int(verbose), mt_count, split_count
     if to_dir is not None:
         o.to_dir = to_dir.encode()
-    o.device_streams, o.hbm_budget = device_streams, hbm_budget
+    o.device_streams, o.hbm_budget, o.task_bytes = device_streams, hbm_budget, task_bytes
     return o
 
 

@@ -296,6 +296,36 @@ bool ext_less(Index::iterator a, Index::iterator b)
     return a->first < b->first;
 }
 
+// Not in the reference (CSAOptions::task_bytes): cut tasks so that none exceeds `cap` bytes.  A file larger than
+// the room left in a task continues in the next one as another fragment; a file is never cut into more than 127
+// fragments (the index stores the count in one signed byte, csa_indexpack.cpp:84,105).
+std::vector<Task> cap_tasks(const std::vector<Task> &in, uint64_t cap)
+{
+    std::vector<Task> out;
+    for (const Task &t : in) {
+        Task cur;
+        for (const FilePiece &f : t.files) {
+            const uint64_t min_piece = (f.size + 126) / 127;           // keeps the fragment count <= 127
+            uint64_t off = f.off, left = f.size;
+            if (left == 0) { cur.add(f.path, off, 0, 0, 0, f.it); continue; }
+            while (left) {
+                uint64_t room = cur.total < cap ? cap - cur.total : 0;
+                if (room < std::min<uint64_t>(left, std::max<uint64_t>(min_piece, 1)) && cur.total) {
+                    out.push_back(cur);
+                    cur = Task();
+                    continue;
+                }
+                uint64_t n = std::min<uint64_t>(left, std::max<uint64_t>(room, min_piece));
+                cur.add(f.path, off, n, 0, 0, f.it);
+                off += n; left -= n;
+            }
+        }
+        if (!cur.files.empty()) out.push_back(cur);
+    }
+    std::sort(out.begin(), out.end(), [](const Task &a, const Task &b) { return a.total > b.total; });
+    return out;
+}
+
 std::vector<Task> plan_tasks(Index &index, int split_count)
 {
     std::vector<Index::iterator> order;
@@ -1043,6 +1073,7 @@ int CSA_Add(const char *arcname, const char *const *filenames, int nfilenames, c
     Index index;
     for (const std::string &f : sel.names) scan_path(index, sel, f, o.recurse != 0);
     std::vector<Task> tasks = plan_tasks(index, o.split_count);
+    if (o.task_bytes) tasks = cap_tasks(tasks, o.task_bytes);
 
     int fd = open(arcname, O_RDWR | O_CREAT, 0666);                          // OutputFile::open: "rb+" else "wb+"
     if (fd < 0) { perror(arcname); return WRITE_ERROR; }

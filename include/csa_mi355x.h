@@ -47,6 +47,12 @@ typedef struct CSAOptions {
                                fit the HBM budget (at most 1024)                                     */
     uint64_t hbm_budget;    /* Add: bytes of HBM the concurrent task encoders may use; 0 = 3/4 of
                                the free device memory                                                */
+    uint64_t task_bytes;    /* Add: 0 = the reference's task split (archive identical to csarc's).
+                               > 0: tasks are additionally cut so that none exceeds this many bytes
+                               (files are split into fragments where needed).  The archive is then NOT
+                               the one `csarc a` would write, but it is a valid .csa that `csarc x/t/l`
+                               read; it gives the GPU many independent streams on any input.  At most
+                               127 fragments per file are produced (the index format's limit).          */
 } CSAOptions;
 
 typedef struct CSAStats {

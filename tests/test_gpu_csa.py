@@ -241,3 +241,37 @@ def test_damaged_archives(csa, tmp_path, monkeypatch):
     # truncated body: index position beyond the file
     (tmp_path / "t.csa").write_bytes(arc[:len(arc) // 2])
     assert csa.test("t.csa")[0] == -1
+
+
+def test_task_bytes_gives_valid_archives_the_reference_reads(csa, tmp_path, monkeypatch, orc_dec):
+    """CSAOptions.task_bytes (not in the reference): more, smaller tasks -- a different but valid archive"""
+    content = csa_cases.make_tree(str(tmp_path), "mixed_tree")
+    monkeypatch.chdir(tmp_path)
+    spec = csa_cases.CSA_CASES["mixed_tree"]
+    rc, st = csa.add("small.csa", spec["args"], overwrite=True, task_bytes=100000, **spec["opts"])
+    assert rc == 0 and st["n_tasks"] >= 8
+    arc = (tmp_path / "small.csa").read_bytes()
+    assert cases.digest(arc) != GOLD["mixed_tree"]["archive_sha256"]
+    info = orc_csa.parse(arc, orc_dec)
+    assert max(len(e["frags"]) for e in info["index"].values()) >= 2          # some file spans tasks
+    assert all(sum(f["size"] for f in info["index"][n]["frags"]) == len(d) for n, d in content.items())
+    files, bad = orc_csa.extract(arc, orc_dec)                                 # the CPU oracle reads it
+    assert not bad and all(files[n] == d for n, d in content.items())
+    rc, st = csa.test("small.csa", mt_count=4)                                 # the product reads it
+    assert rc == 0 and st["verify_failures"] == 0
+    out = tmp_path / "o"
+    assert csa.extract("small.csa", to_dir=str(out), mt_count=4)[0] == 0
+    for n, d in content.items():
+        assert (out / n).read_bytes() == d
+    if HAVE_REF:                                                               # and so does the reference
+        t = subprocess.run([CSARC_REF, "t", "small.csa"], cwd=tmp_path, capture_output=True)
+        assert t.returncode == 0 and b"failed" not in t.stderr
+        subprocess.run([CSARC_REF, "x", "-o", "r", "small.csa"], cwd=tmp_path, check=True, capture_output=True)
+        for n, d in content.items():
+            assert (tmp_path / "r" / n).read_bytes() == d
+    # one huge file: never more than 127 fragments
+    (tmp_path / "big.bin").write_bytes(cases.build([["text", 3, 0, 3 << 20]]))
+    rc, st = csa.add("big.csa", ["big.bin"], overwrite=True, task_bytes=4096, level=1, dict_size=64 << 10)
+    assert rc == 0 and st["n_tasks"] == 127
+    rc, st = csa.test("big.csa", mt_count=16)
+    assert rc == 0 and st["verify_failures"] == 0 and st["raw_bytes"] == 3 << 20
