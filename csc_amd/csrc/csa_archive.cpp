@@ -25,7 +25,6 @@
 #include <map>
 #include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/csc_mi355x.h"
@@ -848,23 +847,45 @@ struct FragSink {
     static size_t write_cb(void *p, const void *buf, size_t size) { return ((FragSink *)p)->put((const uint8_t *)buf, size); }
 };
 
-// DecompressionWorker::do_work, csa_worker.cpp:59-90
-int decode_task(int arc_fd, Task &t, const std::vector<Extent> &ext, std::atomic<uint32_t> *failures)
+// DecompressionWorker::do_work, csa_worker.cpp:59-90, for a WAVE of tasks: every task gets its own source, sink
+// and decoder handle exactly as one worker would set them up; then all of them are decoded together, one kernel
+// launch per round (CSCMI_DecodeBatch).  Returns the worst return code of the wave (0 = all fine).
+int decode_wave(int arc_fd, std::vector<Task> &tasks, size_t first, size_t count, const BlockIndex &abindex,
+                std::atomic<uint32_t> *failures)
 {
-    ExtentSource src(arc_fd, &ext);
-    FragSink sink(&t.files, failures);
-    uint8_t hdr[CSC_PROP_SIZE];
-    size_t n = CSC_PROP_SIZE;
-    src.is.Read(&src.is, hdr, &n);
-    if (n != CSC_PROP_SIZE) return DECODE_ERROR;
-    CSCProps p;
-    CSCDec_ReadProperties(&p, hdr);
-    CSCDecHandle h = CSCDec_Create(&p, &src.is, NULL);
-    if (!h) return DECODE_ERROR;
-    int rc = CSCDec_Decode(h, &sink.os, NULL);
-    CSCDec_Destroy(h);
-    sink.finish();
-    return rc;
+    static const std::vector<Extent> kNoBlocks;
+    std::vector<ExtentSource *> srcs;
+    std::vector<FragSink *> sinks;
+    std::vector<CSCDecHandle> hs;
+    std::vector<ISeqOutStream *> oss;
+    int worst = 0;
+    for (size_t t = first; t < first + count; t++) {
+        auto ab = abindex.find(tasks[t].ab_id);
+        ExtentSource *src = new ExtentSource(arc_fd, ab == abindex.end() ? &kNoBlocks : &ab->second);
+        FragSink *sink = new FragSink(&tasks[t].files, failures);
+        srcs.push_back(src);
+        sinks.push_back(sink);
+        uint8_t hdr[CSC_PROP_SIZE];
+        size_t n = CSC_PROP_SIZE;
+        src->is.Read(&src->is, hdr, &n);                                    // csa_worker.cpp:77-80
+        CSCDecHandle h = NULL;
+        if (n == CSC_PROP_SIZE) {
+            CSCProps p;
+            CSCDec_ReadProperties(&p, hdr);
+            h = CSCDec_Create(&p, &src->is, NULL);
+        }
+        if (!h) { worst = DECODE_ERROR; continue; }
+        hs.push_back(h);
+        oss.push_back(&sink->os);
+    }
+    std::vector<int> rcs(hs.size(), 0);
+    int rc = CSCMI_DecodeBatch((int)hs.size(), hs.data(), oss.data(), rcs.data());
+    if (rc < 0) worst = rc;
+    for (int r : rcs) if (r < 0) worst = r;
+    for (CSCDecHandle h : hs) CSCDec_Destroy(h);
+    for (FragSink *k : sinks) { k->finish(); delete k; }
+    for (ExtentSource *x : srcs) delete x;
+    return worst;
 }
 
 // Extract / Test share everything but the output names: csarc.cpp:600-650, :667-700, decompress_mt :411-470
@@ -918,30 +939,28 @@ int read_archive(const char *arcname, const Selection &sel, const CSAOptions &o,
 
     int arc_fd = open(arcname, O_RDONLY);
     if (arc_fd < 0) return -1;
-    int device = 0;
-    (void)hipGetDevice(&device);
-    int nthreads = o.mt_count < 1 ? 1 : (o.mt_count > 64 ? 64 : o.mt_count);
-    nthreads = (int)std::min<size_t>((size_t)nthreads, std::max<size_t>(tasks.size(), 1));
-    std::atomic<size_t> next(0);
-    std::atomic<int> worst(0);
+    // waves of tasks, largest first (csarc.cpp:430): as many streams per launch as there are CUs, within the HBM budget
+    size_t mem_free = 0, mem_total = 0;
+    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { close(arc_fd); return CSCMI_DEVICE_ERROR; }
+    const uint64_t budget = o.hbm_budget ? o.hbm_budget : (uint64_t)mem_free / 4 * 3;
+    const size_t width = o.device_streams > 0 ? (size_t)o.device_streams : 256;
     std::atomic<uint32_t> failures(0);
-    static const std::vector<Extent> kNoBlocks;
-    auto worker = [&]() {
-        (void)hipSetDevice(device);
-        for (;;) {
-            size_t i = next.fetch_add(1);
-            if (i >= tasks.size()) break;
-            auto ab = abindex.find(tasks[i].ab_id);
-            int r = decode_task(arc_fd, tasks[i], ab == abindex.end() ? kNoBlocks : ab->second, &failures);
-            if (r < 0) worst.store(r);
-        }
-    };
+    int worst = 0;
     double t1 = now_s();
-    if (nthreads <= 1) worker();
-    else {
-        std::vector<std::thread> th;
-        for (int i = 0; i < nthreads; i++) th.emplace_back(worker);
-        for (auto &t : th) t.join();
+    for (size_t first = 0; first < tasks.size();) {
+        size_t count = 0;
+        uint64_t mem = 0;
+        while (first + count < tasks.size() && count < width) {
+            // a decoder holds the dictionary (unknown before its header is read; bounded by the task's raw size
+            // and by 1 GiB) plus ~24 MiB of rings and buffers
+            uint64_t need = std::min<uint64_t>(std::max<uint64_t>(tasks[first + count].total, 1u << 20), 1ull << 30) + (24ull << 20);
+            if (count && mem + need > budget) break;
+            mem += need;
+            count++;
+        }
+        int r = decode_wave(arc_fd, tasks, first, count, abindex, &failures);
+        if (r < 0) worst = r;
+        first += count;
     }
     close(arc_fd);
     if (st) {
@@ -952,7 +971,7 @@ int read_archive(const char *arcname, const Selection &sel, const CSAOptions &o,
         st->seconds_encode = now_s() - t1;
         st->seconds_total = now_s() - t0;
     }
-    if (worst.load() < 0) {
+    if (worst < 0) {
         fprintf(stderr, "Extraction error, archive corrupted\n");           // csarc.cpp:464-467
         return -1;
     }

@@ -12,9 +12,12 @@
 // No CPU decoding path exists in this library.
 #include <hip/hip_runtime.h>
 
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <vector>
 
 #include "../../include/csc_mi355x.h"
 #include "csc_device.h"
@@ -22,6 +25,7 @@
 namespace cscmi {
 void launch_decode_init(DecState *D, hipStream_t st);
 void launch_decode_run(DecState *D, hipStream_t st);
+void launch_decode_run_multi(DecState *const *states, uint32_t n, hipStream_t st);
 }
 using namespace cscmi;
 
@@ -119,7 +123,7 @@ int decompress(DecInstance *x, uint32_t *size)
         if (hipMemcpyAsync(&x->d_state->avail[0], x->avail, sizeof(x->avail), hipMemcpyHostToDevice, x->stream) != hipSuccess) return CSCMI_DEVICE_ERROR;
         launch_decode_run(x->d_state, x->stream);
         if (hipGetLastError() != hipSuccess) return CSCMI_DEVICE_ERROR;
-        if (hipMemcpyAsync(x->h_read, x->d_state, sizeof(DecState), hipMemcpyDeviceToHost, x->stream) != hipSuccess) return CSCMI_DEVICE_ERROR;
+        if (hipMemcpyAsync(x->h_read, x->d_state, offsetof(DecState, probs), hipMemcpyDeviceToHost, x->stream) != hipSuccess) return CSCMI_DEVICE_ERROR;
         if (hipStreamSynchronize(x->stream) != hipSuccess) return CSCMI_DEVICE_ERROR;
         const DecState &r = *x->h_read;
         x->taken[0] = r.taken[0]; x->taken[1] = r.taken[1];
@@ -229,6 +233,92 @@ int CSCDec_Decode(CSCDecHandle p, ISeqOutStream *os, ICompressProgress *progress
         if (wrote < size) { ret = WRITE_ERROR; break; }
     }
     return ret;
+}
+
+// development aid (section timers of a -DCSCMI_TIMERS build; zeros in the product build)
+void CSCMI_DebugDecTimers(CSCDecHandle p, uint64_t *out16)
+{
+    DecInstance *x = (DecInstance *)p;
+    (void)hipMemcpy(out16, (const uint8_t *)x->d_state + offsetof(DecState, dbg), 16 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+}
+
+// Not in the reference: CSCDec_Decode for n independent handles at once (the tasks of an archive).  Every round
+// is ONE launch of k_decode_run_multi -- workgroup b advances stream b until it needs a block or has completed a
+// Decompress call -- followed, per stream and on this thread, by exactly the callbacks CSCDec_Decode would make:
+// the block reads MemIO::ReadBlock does for that stream, or the Write of its decoded run.  rcs[i] receives what
+// CSCDec_Decode(hs[i], oss[i], NULL) would have returned.  Returns 0, or CSCMI_DEVICE_ERROR if the GPU side failed.
+int CSCMI_DecodeBatch(int n, CSCDecHandle *hs, ISeqOutStream *const *oss, int *rcs)
+{
+    if (n <= 0) return 0;
+    DecInstance *lead = (DecInstance *)hs[0];
+    if (hipSetDevice(lead->device) != hipSuccess) return CSCMI_DEVICE_ERROR;
+    hipStream_t st = lead->stream;
+    DecState **d_list = nullptr, **h_list = nullptr;
+    if (hipMalloc((void **)&d_list, sizeof(DecState *) * n) != hipSuccess) return CSCMI_DEVICE_ERROR;
+    if (hipHostMalloc((void **)&h_list, sizeof(DecState *) * n, hipHostMallocDefault) != hipSuccess) { (void)hipFree(d_list); return CSCMI_DEVICE_ERROR; }
+    std::vector<int> live;
+    for (int i = 0; i < n; i++) { rcs[i] = 0; live.push_back(i); }
+    int dev_rc = 0;
+    while (!live.empty() && !dev_rc) {
+        bool ok = true;
+        for (size_t k = 0; k < live.size() && ok; k++) {
+            DecInstance *x = (DecInstance *)hs[live[k]];
+            for (int q = 0; q < 2 && ok; q++)
+                ok = hipMemcpyAsync(x->h.qsize[q], x->h_qsize[q], sizeof(uint32_t) * x->h.qslots, hipMemcpyHostToDevice, st) == hipSuccess;
+            ok = ok && hipMemcpyAsync(&x->d_state->avail[0], x->avail, sizeof(x->avail), hipMemcpyHostToDevice, st) == hipSuccess;
+            h_list[k] = x->d_state;
+        }
+        ok = ok && hipMemcpyAsync(d_list, h_list, sizeof(DecState *) * live.size(), hipMemcpyHostToDevice, st) == hipSuccess;
+        if (ok) {
+            launch_decode_run_multi(d_list, (uint32_t)live.size(), st);
+            ok = hipGetLastError() == hipSuccess;
+        }
+        for (size_t k = 0; k < live.size() && ok; k++) {
+            DecInstance *x = (DecInstance *)hs[live[k]];
+            ok = hipMemcpyAsync(x->h_read, x->d_state, offsetof(DecState, probs), hipMemcpyDeviceToHost, st) == hipSuccess;
+        }
+        ok = ok && hipStreamSynchronize(st) == hipSuccess;
+        if (!ok) { dev_rc = CSCMI_DEVICE_ERROR; break; }
+        // decoded runs back in one go
+        for (int i : live) {
+            DecInstance *x = (DecInstance *)hs[i];
+            const DecState &r = *x->h_read;
+            if (r.status == DEC_DONE && r.out_size)
+                ok = ok && hipMemcpyAsync(x->h_out, x->h.out, r.out_size, hipMemcpyDeviceToHost, st) == hipSuccess;
+        }
+        ok = ok && hipStreamSynchronize(st) == hipSuccess;
+        if (!ok) { dev_rc = CSCMI_DEVICE_ERROR; break; }
+        std::vector<int> next;
+        for (int i : live) {
+            DecInstance *x = (DecInstance *)hs[i];
+            const DecState &r = *x->h_read;
+            x->taken[0] = r.taken[0]; x->taken[1] = r.taken[1];
+            x->consumed_view = r.consumed + r.rd[0] + r.rd[1];
+            bool keep = false;
+            switch (r.status) {
+            case DEC_DONE:
+                if (r.out_size) {                                           // csc_dec.cpp:760-771
+                    size_t wrote = oss[i]->Write(oss[i], x->h_out, r.out_size);
+                    if (wrote == CSC_WRITE_ABORT) break;
+                    if (wrote < r.out_size) { rcs[i] = WRITE_ERROR; break; }
+                    keep = true;
+                }
+                break;
+            case DEC_NEED_RC:
+            case DEC_NEED_BC:
+                if (read_block(x, r.status == DEC_NEED_RC ? 1 : 0) < 0) rcs[i] = r.phase == DEC_PH_PRIME ? -1 : READ_ERROR;
+                else keep = true;
+                break;
+            case DEC_ERR_MINUS1: rcs[i] = -1; break;
+            default: rcs[i] = DECODE_ERROR;
+            }
+            if (keep) next.push_back(i);
+        }
+        live.swap(next);
+    }
+    (void)hipFree(d_list);
+    (void)hipHostFree(h_list);
+    return dev_rc;
 }
 
 }  // extern "C"

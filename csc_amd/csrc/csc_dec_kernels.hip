@@ -20,27 +20,52 @@ namespace cscmi {
 
 #define DDEV __device__ __forceinline__
 #define DUNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+// A taken scalar branch costs a lone wavefront ~35 cycles (tools/ub/ub_issue.hip), a dependent SALU op ~4: rare paths
+// are marked so that the hot path is the fall-through one, and short alternatives are written as selects.
+#define LIKELY(x) __builtin_expect(!!(x), 1)
+#define UNLIKELY(x) __builtin_expect(!!(x), 0)
 typedef __attribute__((address_space(1))) uint8_t dgu8;
 typedef __attribute__((address_space(1))) uint32_t dgu32;
+typedef __attribute__((address_space(1))) DecState gDecState;   // the stream state, known to live in global memory
 
+// LDS image of one stream (dynamic shared memory, 138 KiB: one stream per CU).  The order-1 literal table --
+// 65 536 twelve-bit probabilities, the table every literal walks 8 levels of -- lives here as u16 for the whole
+// launch (HBM image: DecState::p_lit reinterpreted as u16[65536]); so do the small tables and the head of the
+// undo journal.  p_delta (DT_DLT runs only) stays in HBM.
+constexpr uint32_t kUjLds = 256;
 struct DecLds {
     uint32_t P[P_COUNT + 4];
     uint32_t wtab[128];   // the dictionary filter's words, 4 chars packed per entry (0-terminated)
+    uint2 uj[kUjLds];     // undo journal, first kUjLds entries of a packet: (table | index, old value)
+    uint16_t plit[65536];
 };
+constexpr uint32_t kDecLdsBytes = sizeof(DecLds);
+
+#ifdef CSCMI_TIMERS
+#define DTM_DECL unsigned long long dtm__ = __builtin_readcyclecounter()
+#define DTM_ADD(c, k) do { unsigned long long n__ = __builtin_readcyclecounter(); (c).tm[k] += n__ - dtm__; (c).tm[8 + (k)]++; dtm__ = n__; } while (0)
+#else
+#define DTM_DECL do {} while (0)
+#define DTM_ADD(c, k) do {} while (0)
+#endif
 
 struct Dc {
-    DecState *D;
+#ifdef CSCMI_TIMERS
+    unsigned long long tm[16];
+#endif
+    gDecState *D;
     DecLds *L;
     dgu8 *wnd, *out, *q[2];
-    dgu32 *p_lit, *p_delta, *qsize[2], *undo_addr, *undo_val;
+    dgu32 *p_delta, *qsize[2], *undo_addr, *undo_val;
     uint32_t wnd_size, bsize, qslots, lane;
     uint32_t avail[2], taken[2], rd[2], fill[2];
     uint32_t range, code, bc_bits, bc_val, state, ctx, rep[4], wnd_pos;
     uint64_t consumed;
     uint32_t need;      // 0, or DEC_NEED_RC / DEC_NEED_BC once a block ran out with no successor uploaded
     uint32_t err;       // DECODE_ERROR-class failure inside a packet
-    uint32_t undo_n;
-    uint32_t bv[2], bbase[2], btag[2];   // 64 bytes of the current RC / BC block, one per lane: block bytes [bbase, bbase+64) of block #btag
+    uint32_t undo_n;    // bits decoded in this packet (= journal entries when `careful`)
+    uint32_t careful;   // journal the probability updates of this packet (it may run out of input and be rolled back)
+    uint32_t bv[2], woff[2];   // 64 bytes of the current RC / BC block, one per lane, and the read offset inside them (64 = refetch)
     // resume variables of the Decompress call in flight (mirrors of DecState fields)
     uint32_t phase, type, run_size, i, copied, copied_from, status, out_size, p_delta_ready;
 };
@@ -60,18 +85,25 @@ DDEV void ck_take(Dc &c, Ck &k)
     k.state = c.state; k.ctx = c.ctx; k.wnd_pos = c.wnd_pos; k.consumed = c.consumed;
     for (int i = 0; i < 4; i++) k.rep[i] = c.rep[i];
     c.undo_n = 0;
+    c.careful = 1;
 }
-// undo the probability updates made since the checkpoint and restore the scalars
+// undo the probability updates made since the checkpoint and restore the scalars.
+// journal address: bits 31:30 = table (0 small tables in LDS, 1 p_lit in LDS, 2 p_delta in HBM)
 DDEV void ck_rollback(Dc &c, const Ck &k)
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     for (uint32_t n = c.undo_n; n > 0; n--) {
-        uint32_t a = DUNI(c.undo_addr[n - 1]), v = DUNI(c.undo_val[n - 1]);
-        if (a & 0x80000000u) c.p_lit[a & 0x7FFFFFFFu] = v;   // p_lit and p_delta are one allocation
-        else c.L->P[a] = v;
+        uint32_t a, v;
+        if (n - 1 < kUjLds) { uint2 e = c.L->uj[n - 1]; a = DUNI(e.x); v = DUNI(e.y); }
+        else { a = DUNI(c.undo_addr[n - 1 - kUjLds]); v = DUNI(c.undo_val[n - 1 - kUjLds]); }
+        const uint32_t sp = a >> 30, idx = a & 0x3FFFFFFFu;
+        if (sp == 0) c.L->P[idx] = v;
+        else if (sp == 1) c.L->plit[idx] = (uint16_t)v;
+        else c.p_delta[idx] = v;
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     c.undo_n = 0;
-    for (int i = 0; i < 2; i++) { c.taken[i] = k.taken[i]; c.rd[i] = k.rd[i]; c.fill[i] = k.fill[i]; c.btag[i] = 0xFFFFFFFFu; }
+    for (int i = 0; i < 2; i++) { c.taken[i] = k.taken[i]; c.rd[i] = k.rd[i]; c.fill[i] = k.fill[i]; c.woff[i] = 64; }
     c.range = k.range; c.code = k.code; c.bc_bits = k.bc_bits; c.bc_val = k.bc_val;
     c.state = k.state; c.ctx = k.ctx; c.wnd_pos = k.wnd_pos; c.consumed = k.consumed;
     for (int i = 0; i < 4; i++) c.rep[i] = k.rep[i];
@@ -81,25 +113,24 @@ DDEV void ck_rollback(Dc &c, const Ck &k)
 // DecodeBit / coder_decode_direct do (csc_dec.cpp:14-21, 70-76)
 DDEV uint32_t next_byte(Dc &c, int kind)
 {
-    if (c.need) return 0;
+    if (UNLIKELY(c.need)) return 0;
     // bytes are served from a 64-byte register window over the current block (one HBM fetch per 64 bytes)
-    uint32_t off = c.rd[kind] - c.bbase[kind];
-    if (c.btag[kind] != c.taken[kind] || off >= 64) {
+    if (UNLIKELY(c.woff[kind] >= 64)) {
         uint32_t slot = (c.taken[kind] - 1) % c.qslots;
-        c.bbase[kind] = c.rd[kind];
-        c.btag[kind] = c.taken[kind];
         c.bv[kind] = c.q[kind][(size_t)slot * c.bsize + c.rd[kind] + c.lane];   // ring has 64 bytes of slack
-        off = 0;
+        c.woff[kind] = 0;
     }
-    uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)c.bv[kind], (int)off);
+    uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)c.bv[kind], (int)c.woff[kind]);
+    c.woff[kind]++;
     c.rd[kind]++;
-    if (c.rd[kind] >= c.fill[kind]) {
+    if (UNLIKELY(c.rd[kind] >= c.fill[kind])) {
         if (c.taken[kind] < c.avail[kind]) {
             c.consumed += c.rd[kind];
             uint32_t ns = c.taken[kind] % c.qslots;
             c.fill[kind] = DUNI(c.qsize[kind][ns]);
             c.taken[kind]++;
             c.rd[kind] = 0;
+            c.woff[kind] = 64;
         } else {
             c.need = kind ? DEC_NEED_RC : DEC_NEED_BC;
         }
@@ -107,30 +138,67 @@ DDEV uint32_t next_byte(Dc &c, int kind)
     return b;
 }
 
-// DecodeBit (csc_dec.cpp:10-35): space 0 = small tables in LDS, 1 = p_lit / p_delta words in HBM
-DDEV uint32_t dbit_p(Dc &c, uint32_t v, uint32_t space, uint32_t idx, uint32_t p)
+// ---- bit decoding ---------------------------------------------------------------------------------------------
+// DecodeBit (csc_dec.cpp:10-35) is split in two.  The SERIAL part -- range, code, the bit -- runs on scalars and is
+// all that sits on the dependency chain (rc_bit, ~12 instructions).  The probability UPDATE of the nodes a symbol
+// visited does not feed the chain (a tree visits each node at most once per symbol), so it is done afterwards by the
+// lanes that hold those nodes: one vector update + one LDS store per tree instead of one per bit (tree_update).
+DDEV uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+
+DDEV uint32_t rc_bit(Dc &c, uint32_t p)
 {
-    if (c.range < (1u << 24)) { c.range <<= 8; c.code = (c.code << 8) + next_byte(c, 1); }
-    uint32_t bound = (c.range >> 12) * p, np, bit;
-    if (c.code < bound) { c.range = bound; np = p + ((0xFFFu - p) >> 5); bit = 1; }
-    else { c.range -= bound; c.code -= bound; np = p - (p >> 5); bit = 0; }
-    if (!c.need) {
-        if (c.undo_n < kDecUndoCap) {
-            c.undo_addr[c.undo_n] = idx | (space << 31);
-            c.undo_val[c.undo_n] = p;
-            c.undo_n++;
-        } else {
-            c.err = 1;   // a packet longer than any the encoder can produce
-        }
-        if (space) c.p_lit[idx] = np; else c.L->P[idx] = np;
+    if (UNLIKELY(c.range < (1u << 24))) { c.range <<= 8; c.code = (c.code << 8) + next_byte(c, 1); }
+    const uint32_t bound = (c.range >> 12) * p;
+    const bool one = c.code < bound;
+    c.range = one ? bound : c.range - bound;
+    c.code = one ? c.code : c.code - bound;
+    return one ? 1u : 0u;
+}
+// p += (0xFFF - p) >> 5 or p -= p >> 5; 0xFFF - p == p ^ 0xFFF for 12-bit p
+DDEV uint32_t p_update(uint32_t p, uint32_t bit)
+{
+    const uint32_t d = (p ^ (bit ? 0xFFFu : 0u)) >> 5;
+    return bit ? p + d : p - d;
+}
+// journal address: bits 31:30 = table (0 small tables in LDS, 1 p_lit in LDS, 2 p_delta in HBM)
+DDEV void journal_put(Dc &c, uint32_t slot, uint32_t addr, uint32_t old)
+{
+    if (slot < kUjLds) c.L->uj[slot] = make_uint2(addr, old);
+    else if (slot < kUjLds + kDecUndoCap) { c.undo_addr[slot - kUjLds] = addr; c.undo_val[slot - kUjLds] = old; }
+}
+template <int SPACE>
+DDEV void p_store(Dc &c, uint32_t idx, uint32_t np)
+{
+    if (SPACE == 0) c.L->P[idx] = np;
+    else if (SPACE == 1) c.L->plit[idx] = (uint16_t)np;
+    else c.p_delta[idx] = np;
+}
+// After an NB-bit tree has been decoded to `v` (leading 1 included): lane-parallel update of the NB nodes on the
+// path.  Each lane holds in `g` the probability of tree node `node` (heap numbering, 1 = root; anything outside
+// [1, 2^NB) = not a node of this tree) stored at table index `idx`.
+template <int NB, int SPACE>
+DDEV void tree_update(Dc &c, uint32_t g, uint32_t v, uint32_t node, uint32_t idx)
+{
+    const uint32_t depth = 31u - (uint32_t)__builtin_clz(node | 1u);       // 0 for the root
+    const uint32_t sh = (uint32_t)NB - depth;                              // v >> sh is the path's node at that depth
+    const bool on = node >= 1u && node < (1u << NB) && (v >> (sh & 31u)) == node;
+    const uint32_t bit = (v >> ((sh - 1u) & 31u)) & 1u;
+    if (on) {
+        if (UNLIKELY(c.careful)) journal_put(c, c.undo_n + depth, idx | ((uint32_t)SPACE << 30), g);
+        p_store<SPACE>(c, idx, p_update(g, bit));
     }
-    return v + v + bit;
+    c.undo_n += NB;
 }
-DDEV uint32_t dbit(Dc &c, uint32_t v, uint32_t space, uint32_t idx)
+// one stand-alone bit under a small-table probability (packet flags, length-slot bits, the long-length escape)
+DDEV uint32_t dbit_p(Dc &c, uint32_t idx, uint32_t p)
 {
-    uint32_t p = space ? DUNI(c.p_lit[idx]) : DUNI(c.L->P[idx]);
-    return dbit_p(c, v, space, idx, p);
+    const uint32_t bit = rc_bit(c, p);
+    if (UNLIKELY(c.careful)) journal_put(c, c.undo_n, idx, p);
+    c.undo_n++;
+    c.L->P[idx] = p_update(p, bit);
+    return bit;
 }
+DDEV uint32_t dbit(Dc &c, uint32_t idx) { return dbit_p(c, idx, DUNI(c.L->P[idx])); }
 
 DDEV uint32_t ddirect16(Dc &c, uint32_t len)   // coder_decode_direct, csc_dec.cpp:65-88
 {
@@ -147,44 +215,75 @@ DDEV uint32_t dget_int(Dc &c)                  // decode_int, csc_dec.cpp:90-97
     uint32_t num = ddirect(c, slot == 0 ? 1 : slot);
     return slot ? num + (1u << slot) : num;
 }
-// 8 bits under an order-1 row of p_lit / p_delta.  The node of bit k depends on the bits before it,
-// so instead of 8 dependent HBM fetches the 15 nodes of the top 4 levels are fetched at once (heap
-// order: lane L = node L), then the 15 nodes of the 4-level subtree under the node reached.
-DDEV uint32_t dbyte_tree(Dc &c, uint32_t row_word)
+
+// 8 bits under an order-1 row.  The node of bit k depends on the bits before it, so instead of 8 dependent
+// fetches the 15 nodes of the top 4 levels are fetched at once (heap order: lane L = node L), then the 15
+// nodes of the 4-level subtree under the node reached.  `top` = the first fetch, issued by the caller.
+template <int SPACE>
+DDEV uint32_t dbyte_tree_from(Dc &c, uint32_t row, uint32_t top)
 {
     const uint32_t L = c.lane & 15;
-    uint32_t pv = c.p_lit[row_word + L];
     uint32_t v = 1;
 #pragma unroll
-    for (int k = 0; k < 4; k++) v = dbit_p(c, v, 1, row_word + v, (uint32_t)__builtin_amdgcn_readlane((int)pv, (int)v));
+    for (int k = 0; k < 4; k++) v = v + v + rc_bit(c, rl(top, v));
     // subtree under node v (16..31): lane L = 2^j + t  ->  node (v << j) + t
     const uint32_t j = 31u - (uint32_t)__builtin_clz(L | 1u);
-    uint32_t pv2 = c.p_lit[row_word + (v << j) + (L - (1u << j))];
+    const uint32_t sidx = row + (v << j) + (L - (1u << j));
+    const uint32_t sub = SPACE == 1 ? (uint32_t)c.L->plit[sidx] : (uint32_t)c.p_delta[sidx];
+    tree_update<4, SPACE>(c, top, v, c.lane < 16 ? L : 0u, row + L);
     uint32_t h = 1;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)pv2, (int)h);
-        uint32_t nv = dbit_p(c, v, 1, row_word + v, p);
-        h = h + h + (nv & 1);
-        v = nv;
-    }
-    return v & 0xFF;
+    for (int k = 0; k < 4; k++) h = h + h + rc_bit(c, rl(sub, h));
+    tree_update<4, SPACE>(c, sub, h, c.lane < 16 ? L : 0u, sidx);
+    return ((v << 4) | (h & 15u)) & 0xFF;
 }
-DDEV uint32_t dmatchlen_1(Dc &c)               // csc_dec.cpp:187-220
+DDEV uint32_t dbyte_tree_l(Dc &c, uint32_t row) { return dbyte_tree_from<1>(c, row, c.L->plit[row + (c.lane & 15)]); }
+DDEV uint32_t dbyte_tree_g(Dc &c, uint32_t row) { return dbyte_tree_from<2>(c, row, c.p_delta[row + (c.lane & 15)]); }   // p_delta row (HBM)
+
+// decode_matchlen_1 (csc_dec.cpp:187-220).  P_LEN_SLOT[2], P_LEN_X1[8], P_LEN_X2[8], P_LEN_X3[128] are
+// contiguous: three lane-parallel LDS reads fetch every node any length can touch.
+DDEV uint32_t dmatchlen_1(Dc &c)
 {
-    uint32_t base, tab, i = 1;
-    if (dbit(c, 0, 0, P_LEN_SLOT) == 0) { tab = P_LEN_X1; base = 0; }
-    else if (dbit(c, 0, 0, P_LEN_SLOT + 1) == 0) { tab = P_LEN_X2; base = 8; }
-    else { tab = P_LEN_X3; base = 16; }
-    uint32_t top = base == 16 ? 0x80 : 0x08;
-    do { i = dbit(c, i, 0, tab + i); } while (i < top);
-    return base + (i & (top - 1));
+    const uint32_t i0 = P_LEN_SLOT + c.lane, i1 = P_LEN_SLOT + 64 + c.lane, i2 = P_LEN_SLOT + 128 + (c.lane & 31);
+    const uint32_t g0 = c.L->P[i0], g1 = c.L->P[i1], g2 = c.L->P[i2];
+    if (dbit_p(c, P_LEN_SLOT, rl(g0, 0)) == 0) {                              // 3-bit tree, lengths 0..7
+        uint32_t i = 1;
+#pragma unroll
+        for (int k = 0; k < 3; k++) i = i + i + rc_bit(c, rl(g0, (P_LEN_X1 - P_LEN_SLOT) + i));
+        tree_update<3, 0>(c, g0, i, i0 - P_LEN_X1, i0);
+        return i & 7u;
+    }
+    if (dbit_p(c, P_LEN_SLOT + 1, rl(g0, 1)) == 0) {                          // 3-bit tree, lengths 8..15
+        uint32_t i = 1;
+#pragma unroll
+        for (int k = 0; k < 3; k++) i = i + i + rc_bit(c, rl(g0, (P_LEN_X2 - P_LEN_SLOT) + i));
+        tree_update<3, 0>(c, g0, i, i0 - P_LEN_X2, i0);
+        return 8u + (i & 7u);
+    }
+    uint32_t i = 1;                                                           // 7-bit tree, lengths 16..143
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const uint32_t o = (P_LEN_X3 - P_LEN_SLOT) + i;                       // 19 .. 145
+        const uint32_t p = o < 64 ? rl(g0, o) : (o < 128 ? rl(g1, o - 64) : rl(g2, o - 128));
+        i = i + i + rc_bit(c, p);
+    }
+    // the 7 path nodes live in up to three registers; every lane checks its own node in each (undo_n advances once)
+    {
+        const uint32_t n0 = c.undo_n;
+        tree_update<7, 0>(c, g0, i, i0 - P_LEN_X3, i0); c.undo_n = n0;
+        tree_update<7, 0>(c, g1, i, i1 - P_LEN_X3, i1); c.undo_n = n0;
+        tree_update<7, 0>(c, g2, i, c.lane < 32 ? i2 - P_LEN_X3 : 0u, i2);
+    }
+    return 16u + (i & 127u);
 }
 DDEV uint32_t dmatchlen_2(Dc &c)               // csc_dec.cpp:222-234
 {
     uint32_t len = dmatchlen_1(c);
-    if (len != 143) return len;
-    while (!c.need && !c.err && !dbit(c, 0, 0, P_LONGLEN)) len += 143;
+    if (LIKELY(len != 143)) return len;
+    while (!c.need && !c.err && !dbit(c, P_LONGLEN)) {
+        len += 143;
+        if (c.undo_n > kDecUndoCap) c.err = 1;   // a packet longer than any the encoder can produce
+    }
     return len + dmatchlen_1(c);
 }
 DDEV void dmatch(Dc &c, uint32_t &dist, uint32_t &len)   // decode_match, csc_dec.cpp:236-283
@@ -195,28 +294,54 @@ DDEV void dmatch(Dc &c, uint32_t &dist, uint32_t &len)   // decode_match, csc_de
     else if (len <= 2) { pos = 16 * (len - 1) + 8; sbits = 4; }
     else if (len <= 5) { pos = 32 * (len - 3) + 8 + 32; sbits = 5; }
     else { pos = 32 * 3 + 8 + 32; sbits = 5; }
+    const uint32_t si = P_DIST + pos + (c.lane & 31);
+    const uint32_t gs = c.L->P[si];                                           // the whole slot tree (<= 31 nodes)
     uint32_t i = 1;
-    do { i = dbit(c, i, 0, P_DIST + pos + i); } while (i < (1u << sbits));
+#pragma unroll
+    for (int k = 0; k < 3; k++) i = i + i + rc_bit(c, rl(gs, i));
+    if (sbits == 3) tree_update<3, 0>(c, gs, i, c.lane < 32 ? c.lane : 0u, si);
+    else if (sbits == 4) { i = i + i + rc_bit(c, rl(gs, i)); tree_update<4, 0>(c, gs, i, c.lane < 32 ? c.lane : 0u, si); }
+    else {
+        i = i + i + rc_bit(c, rl(gs, i));
+        i = i + i + rc_bit(c, rl(gs, i));
+        tree_update<5, 0>(c, gs, i, c.lane < 32 ? c.lane : 0u, si);
+    }
     uint32_t slot = i & ((1u << sbits) - 1);
     if (slot <= 2) dist = slot;
     else {
-        uint32_t ebits = slot - 2, elen = ebits > 4 ? ddirect(c, ebits - 4) : 0;
+        const uint32_t ebits = slot - 2;
+        const uint32_t ei = P_DIST_EXTRA + (ebits - 1) * 16 + (c.lane & 15);
+        const uint32_t ge = c.L->P[ei];                                       // the 15 nodes of the low-bits tree
+        const uint32_t elen = ebits > 4 ? ddirect(c, ebits - 4) : 0;
         i = 1;
-        do { i = dbit(c, i, 0, P_DIST_EXTRA + (ebits - 1) * 16 + i); } while (i < 0x10);
+#pragma unroll
+        for (int k = 0; k < 4; k++) i = i + i + rc_bit(c, rl(ge, i));
+        tree_update<4, 0>(c, ge, i, c.lane < 16 ? c.lane : 0u, ei);
         dist = ((1u << ebits) + 1) + (elen << 4) + (__brev(i & 0x0Fu) >> 28);   // dist_table_[slot] + ... + rev16_table_
     }
     c.state = (c.state * 4 + 1) & 0x3F;
 }
 
 // window copy of a match: dst[j] = src[j] in increasing j, i.e. a pattern repeat when the regions
-// overlap (csc_dec.cpp:513-518) -- lane-parallel with the modulo made explicit
-DDEV void dcopy_match(Dc &c, uint32_t from, uint32_t dist, uint32_t len)
+// overlap (csc_dec.cpp:513-518) -- lane-parallel with the modulo made explicit.  The wait for earlier window
+// stores sits in front of the loads (by now those stores have had a whole packet's decoding time to land);
+// nothing waits behind the stores.  Returns the last byte copied (the next literal context).
+DDEV uint32_t dcopy_match(Dc &c, uint32_t from, uint32_t dist, uint32_t len)
 {
     dgu8 *w = c.wnd;
     const uint32_t to = c.wnd_pos;
     const bool overlap = from < to && from + len > to;   // then dist = to - from < len
-    for (uint32_t j = c.lane; j < len; j += 64) w[to + j] = w[from + (overlap ? j % dist : j)];
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    // earlier window stores of THIS wavefront are ordered before these loads by the hardware (one wavefront's vector
+    // memory operations execute in order through one L1); the fence only pins the compiler's order
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    uint32_t last = 0;
+    if (!overlap) {
+        for (uint32_t j = c.lane; j < len; j += 64) { last = w[from + j]; w[to + j] = (uint8_t)last; }
+    } else {
+        // every source byte is one of the `dist` bytes in front of `to`: fetch those once, then replicate
+        for (uint32_t j = c.lane; j < len; j += 64) { last = w[from + j % dist]; w[to + j] = (uint8_t)last; }
+    }
+    return rl(last, (len - 1) & 63u);
 }
 
 // CSCDecoder::lz_decode body, csc_dec.cpp:476-571, one packet per loop turn, checkpointed per packet
@@ -225,16 +350,29 @@ DDEV void dlz_decode(Dc &c, uint32_t limit)
     uint32_t i = c.i, copied = c.copied, copied_from = c.copied_from;
     Ck k;
     for (; i <= limit;) {
-        ck_take(c, k);
+        DTM_DECL;
+        // A packet is journalled (and the scalars checkpointed) only if the input could run out inside it: fewer than
+        // kDecUndoCap/8 + 64 coded bytes left in the current RC block, or fewer than 16 in the BC block.  Everywhere
+        // else -- 93 % of a 64 KiB block -- a packet cannot exhaust its block before the kDecUndoCap-bit limit stops it.
+        c.careful = (c.rd[1] + kDecUndoCap / 8 + 64 > c.fill[1] || c.rd[0] + 16 > c.fill[0]) ? 1u : 0u;
+        c.undo_n = 0;
+        if (UNLIKELY(c.careful)) ck_take(c, k);
         uint32_t ni = i;
         bool end = false;
         uint32_t wr_kind = 0, wr_from = 0, wr_dist = 0, wr_len = 0, wr_byte = 0;   // deferred window write of this packet
-        if (dbit(c, 0, 0, P_STATE + c.state * 3) == 0) {
-            uint32_t b = dbyte_tree(c, c.ctx * 256);
+        // the three packet-kind flags, the two rep-index flags that can follow (lanes 0-2 / 3-5) and the top of the
+        // literal tree under the current context: one LDS round trip for everything a packet can start with
+        const uint32_t st3 = c.state * 3;
+        const uint32_t fl = c.L->P[(c.lane < 3 ? P_STATE : P_REPDIST - 3) + st3 + (c.lane < 6 ? c.lane : 5)];
+        const uint32_t lrow = c.ctx * 256;
+        const uint32_t ltop = c.L->plit[lrow + (c.lane & 15)];
+        if (dbit_p(c, P_STATE + st3, rl(fl, 0)) == 0) {
+            uint32_t b = dbyte_tree_from<1>(c, lrow, ltop);
             c.ctx = b;
             c.state = (c.state * 4) & 0x3F;
             wr_kind = 1; wr_byte = b; ni = i + 1;
-        } else if (dbit(c, 0, 0, P_STATE + c.state * 3 + 1) == 1) {
+            DTM_ADD(c, 0);
+        } else if (dbit_p(c, P_STATE + st3 + 1, rl(fl, 1)) == 1) {
             uint32_t dist, len;
             dmatch(c, dist, len);
             if (len == 0 && dist == 64) end = true;
@@ -245,40 +383,48 @@ DDEV void dlz_decode(Dc &c, uint32_t limit)
                 if (from >= c.wnd_size || from + len > c.wnd_size || len + i > limit || c.wnd_pos + len > c.wnd_size) c.err = 1;
                 wr_kind = 2; wr_from = from; wr_dist = dist; wr_len = len; ni = i + len;
             }
-        } else if (dbit(c, 0, 0, P_STATE + c.state * 3 + 2) == 0) {
+        } else if (dbit_p(c, P_STATE + st3 + 2, rl(fl, 2)) == 0) {
             c.state = (c.state * 4 + 2) & 0x3F;
             uint32_t from = c.wnd_pos > c.rep[0] ? c.wnd_pos - c.rep[0] : c.wnd_pos + c.wnd_size - c.rep[0];
             if (from > c.wnd_size) c.err = 1;   // the reference reads out of bounds here on corrupt input
             wr_kind = 2; wr_from = from; wr_dist = c.rep[0]; wr_len = 1; ni = i + 1;
         } else {
-            uint32_t kk = 1;
-            do { kk = dbit(c, kk, 0, P_REPDIST + c.state * 3 + kk - 1); } while (kk < 4);
+            uint32_t kk = 2u + dbit_p(c, P_REPDIST + st3, rl(fl, 3));
+            kk = kk + kk + dbit_p(c, P_REPDIST + st3 + kk - 1, rl(fl, 3 + kk - 1));
             uint32_t idx = kk & 3, len = dmatchlen_2(c) + 2;
             c.state = (c.state * 4 + 3) & 0x3F;
             if (len + i > limit) c.err = 1;
-            uint32_t dist = c.rep[idx];
-            for (uint32_t j = idx; j > 0; j--) c.rep[j] = c.rep[j - 1];
+            // move-to-front as selects: a dynamic index would push the whole stream context into scratch memory
+            const uint32_t r0 = c.rep[0], r1 = c.rep[1], r2 = c.rep[2], r3 = c.rep[3];
+            uint32_t dist = idx == 0 ? r0 : idx == 1 ? r1 : idx == 2 ? r2 : r3;
+            c.rep[3] = idx >= 3 ? r2 : r3;
+            c.rep[2] = idx >= 2 ? r1 : r2;
+            c.rep[1] = idx >= 1 ? r0 : r1;
             c.rep[0] = dist;
             uint32_t from = c.wnd_pos >= dist ? c.wnd_pos - dist : c.wnd_pos + c.wnd_size - dist;
             if (from >= c.wnd_size || from + len > c.wnd_size || len + i > limit || c.wnd_pos + len > c.wnd_size) c.err = 1;
             wr_kind = 2; wr_from = from; wr_dist = dist; wr_len = len; ni = i + len;
         }
-        if (c.need) {          // ran out of input inside this packet: take it back, resume here later
+        if (wr_kind == 2) DTM_ADD(c, 1);
+        if (UNLIKELY(c.undo_n > kDecUndoCap)) c.err = 1;
+        if (UNLIKELY(c.err)) { c.status = DEC_ERR_DECODE; return; }
+        if (UNLIKELY(c.need)) {          // ran out of input inside this packet: take it back, resume here later
+            if (!c.careful) { c.status = DEC_ERR_DECODE; return; }   // unreachable: see `careful` above
             ck_rollback(c, k);
             c.i = i; c.copied = copied; c.copied_from = copied_from;
             return;
         }
-        if (c.err) { c.status = DEC_ERR_DECODE; return; }
-        if (end) break;
+        if (UNLIKELY(c.err)) { c.status = DEC_ERR_DECODE; return; }
+        if (UNLIKELY(end)) break;
         if (wr_kind == 1) { c.wnd[c.wnd_pos] = (uint8_t)wr_byte; c.wnd_pos++; }
         else if (wr_kind == 2) {
-            dcopy_match(c, wr_from, wr_dist, wr_len);
+            c.ctx = dcopy_match(c, wr_from, wr_dist, wr_len);
             c.wnd_pos += wr_len;
-            c.ctx = DUNI((uint32_t)c.wnd[c.wnd_pos - 1]);
         }
         i = ni;
-        if (c.wnd_pos > c.wnd_size) { c.status = DEC_ERR_DECODE; return; }
-        if (c.wnd_pos == c.wnd_size) {
+        DTM_ADD(c, 2);
+        if (UNLIKELY(c.wnd_pos > c.wnd_size)) { c.status = DEC_ERR_DECODE; return; }
+        if (UNLIKELY(c.wnd_pos == c.wnd_size)) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             for (uint32_t t = c.lane; t < i - copied; t += 64) c.out[copied + t] = c.wnd[copied_from + t];
             c.wnd_pos = 0;
@@ -286,8 +432,12 @@ DDEV void dlz_decode(Dc &c, uint32_t limit)
             copied = i;
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    for (uint32_t t = c.lane; t < i - copied; t += 64) c.out[copied + t] = c.wnd[copied_from + t];
+    {
+        DTM_DECL;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        for (uint32_t t = c.lane; t < i - copied; t += 64) c.out[copied + t] = c.wnd[copied_from + t];
+        DTM_ADD(c, 3);
+    }
     c.out_size = i;
     c.i = 0; c.copied = 0; c.copied_from = 0;
     c.phase = DEC_PH_POST;
@@ -366,35 +516,77 @@ DDEV void dinverse_delta(Dc &c, uint32_t size, uint32_t chn)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 }
 
-// Inverse_Dict (csc_filters.cpp:337-369): expand word symbols; 254 escapes a byte >= 0x82.  64 source
-// bytes are fetched per step (one per lane) and walked with readlane; the walk itself is serial
-// because an escape swallows the byte after it.
+// Inverse_Dict (csc_filters.cpp:337-369): expand word symbols; 254 escapes a byte >= 0x82.
+// 64 source bytes per step, one per lane.  Which bytes are escaped follows from the parity of the run of 254s in
+// front of them (a 254 is an escape marker iff it is not itself escaped and the next byte is >= 0x82, so inside a
+// run markers and escaped bytes alternate); every lane then knows how many bytes it emits (0 marker, 1, or a
+// 2-4 letter word), an exclusive wave scan gives its output offset, and it stores its bytes.  The last 66 source
+// positions -- where the reference's `i + 1 < size` guard matters -- are walked serially like the reference does.
 DDEV void dinverse_dict(Dc &c, uint32_t size)
 {
     dgu8 *src = c.out, *dst = (dgu8 *)c.D->swap;
     uint32_t i = 0, o = 0;
-    while (o < size) {
-        const uint32_t base = i;
-        uint32_t v = src[base + c.lane];                 // `out` has 128 bytes of slack
-        uint32_t vn = DUNI((uint32_t)src[base + 64]);
-        uint32_t j = 0;
-        while (j < 64 && o < size) {
-            uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)j);
-            if (b >= 0x82 && b < 0x82 + 122) {
-                uint32_t w = DUNI(c.L->wtab[b - 0x82]);
-                for (uint32_t t = 0; t < 4 && o < size; t++) {
-                    uint32_t ch = (w >> (8 * t)) & 0xFF;
-                    if (!ch) break;
-                    dst[o++] = (uint8_t)ch;
-                }
-            } else {
-                uint32_t nb = j + 1 < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(j + 1)) : vn;
-                if (b == 254 && base + j + 1 < size && nb >= 0x82) { j++; dst[o++] = (uint8_t)nb; }
-                else dst[o++] = (uint8_t)b;
-            }
-            j++;
+    uint32_t carry = 0;                                  // parity of the run of 254s that ends just before position i
+    while (o < size && i + 66 < size) {
+        const uint32_t b = src[i + c.lane];              // `out` has slack behind `size`
+        const uint32_t nb_lane63 = DUNI((uint32_t)src[i + 64]);
+        const uint64_t m254 = __ballot(b == 254);
+        // r = number of consecutive 254s immediately below this lane (run reaching the chunk start continues the carry)
+        const uint64_t below = c.lane ? (m254 << (64 - c.lane)) : 0ull;            // bits [0, lane) moved to the top
+        uint32_t r = c.lane ? (uint32_t)__builtin_clzll(~below | ((1ull << (64 - c.lane)) - 1ull)) : 0u;
+        if (r > c.lane) r = c.lane;
+        const uint32_t par = (r + (r == c.lane ? carry : 0u)) & 1u;
+        const bool ge82 = b >= 0x82;
+        const bool esc = par && ge82;                                                 // swallowed by the marker before it
+        uint32_t nb = (uint32_t)__shfl_down((int)b, 1);
+        if (c.lane == 63) nb = nb_lane63;
+        const bool marker = b == 254 && !esc && nb >= 0x82;
+        const bool word = !esc && b >= 0x82 && b < 0x82 + 122;
+        const uint32_t w = word ? c.L->wtab[b - 0x82] : b;
+        const uint32_t wl = word ? ((w >> 16) & 0xFF ? ((w >> 24) ? 4u : 3u) : 2u) : 1u;   // words have 2..4 letters
+        const uint32_t n = marker ? 0u : wl;
+        uint32_t x = n;                                                               // inclusive scan over the wave
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)x, off); if ((int)c.lane >= off) x += t; }
+        const uint32_t at = o + x - n;
+        for (uint32_t t = 0; t < n; t++) if (at + t < size) dst[at + t] = (uint8_t)(w >> (8 * t));
+        // carry for the next chunk: parity of the run of 254s at the top of this one
+        const uint32_t lead = m254 == ~0ull ? 64u : (uint32_t)__builtin_clzll(~m254);
+        carry = (lead == 64 ? carry + 64u : lead) & 1u;
+        // a trailing marker in lane 63 swallows the first byte of the next chunk: that is what carry expresses
+        o += DUNI((uint32_t)__shfl((int)x, 63));
+        i += 64;
+    }
+    // serial tail (and the whole run if it is shorter than 66 bytes); `carry` odd = position i is an escaped byte
+    {
+        bool escaped = false;
+        if (carry & 1u) {
+            // the run of 254s before i has odd length: its last 254 is a marker iff src[i] >= 0x82
+            escaped = DUNI((uint32_t)src[i]) >= 0x82;
         }
-        i = base + j;
+        while (o < size) {
+            const uint32_t base = i;
+            uint32_t v = src[base + c.lane];
+            uint32_t vn = DUNI((uint32_t)src[base + 64]);
+            uint32_t j = 0;
+            while (j < 64 && o < size) {
+                uint32_t b = rl(v, j);
+                if (escaped) { dst[o++] = (uint8_t)b; escaped = false; }
+                else if (b >= 0x82 && b < 0x82 + 122) {
+                    uint32_t w = DUNI(c.L->wtab[b - 0x82]);
+                    for (uint32_t t = 0; t < 4 && o < size; t++) {
+                        uint32_t ch = (w >> (8 * t)) & 0xFF;
+                        if (!ch) break;
+                        dst[o++] = (uint8_t)ch;
+                    }
+                } else {
+                    uint32_t nb = j + 1 < 64 ? rl(v, j + 1) : vn;
+                    if (b == 254 && base + j + 1 < size && nb >= 0x82) { j++; dst[o++] = (uint8_t)nb; }
+                    else dst[o++] = (uint8_t)b;
+                }
+                j++;
+            }
+            i = base + j;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     for (uint32_t t = c.lane; t < size; t += 64) src[t] = dst[t];
@@ -406,6 +598,7 @@ DDEV bool dprime(Dc &c)
 {
     if (c.taken[1] >= c.avail[1]) { c.need = DEC_NEED_RC; return false; }
     if (c.taken[0] >= c.avail[0]) { c.need = DEC_NEED_BC; return false; }
+#pragma unroll
     for (int kind = 1; kind >= 0; kind--) {
         uint32_t ns = c.taken[kind] % c.qslots;
         c.fill[kind] = DUNI(c.qsize[kind][ns]);
@@ -419,13 +612,12 @@ DDEV bool dprime(Dc &c)
     return true;
 }
 
-__global__ __launch_bounds__(64) void k_decode_run(DecState *D)
+DDEV void decode_stream(gDecState *D, DecLds &lds)
 {
-    __shared__ DecLds lds;
     Dc c;
     c.D = D; c.L = &lds; c.lane = threadIdx.x;
     c.wnd = (dgu8 *)D->wnd; c.out = (dgu8 *)D->out; c.q[0] = (dgu8 *)D->q[0]; c.q[1] = (dgu8 *)D->q[1];
-    c.p_lit = (dgu32 *)D->p_lit; c.p_delta = (dgu32 *)D->p_delta;
+    c.p_delta = (dgu32 *)D->p_delta;
     c.qsize[0] = (dgu32 *)D->qsize[0]; c.qsize[1] = (dgu32 *)D->qsize[1];
     c.undo_addr = (dgu32 *)D->undo_addr; c.undo_val = (dgu32 *)D->undo_val;
     c.wnd_size = D->wnd_size; c.bsize = D->bsize; c.qslots = D->qslots;
@@ -433,8 +625,12 @@ __global__ __launch_bounds__(64) void k_decode_run(DecState *D)
     c.range = D->range; c.code = D->code; c.bc_bits = D->bc_bits; c.bc_val = D->bc_val;
     c.state = D->state; c.ctx = D->ctx; c.wnd_pos = D->wnd_pos; c.consumed = D->consumed;
     for (int i = 0; i < 4; i++) c.rep[i] = D->rep[i];
-    c.need = 0; c.err = 0; c.undo_n = 0;
-    c.bv[0] = c.bv[1] = 0; c.bbase[0] = c.bbase[1] = 0; c.btag[0] = c.btag[1] = 0xFFFFFFFFu;
+#ifdef CSCMI_TIMERS
+    for (int i = 0; i < 16; i++) c.tm[i] = 0;
+    unsigned long long tk0 = __builtin_readcyclecounter();
+#endif
+    c.need = 0; c.err = 0; c.undo_n = 0; c.careful = 1;
+    c.bv[0] = c.bv[1] = 0; c.woff[0] = c.woff[1] = 64;
     c.phase = D->phase; c.type = D->type; c.run_size = D->run_size; c.i = D->i; c.copied = D->copied; c.copied_from = D->copied_from;
     c.out_size = D->out_size; c.p_delta_ready = D->p_delta_ready; c.status = DEC_RUNNING;
     for (uint32_t i = c.lane; i < P_COUNT; i += 64) lds.P[i] = D->probs[i];
@@ -442,6 +638,13 @@ __global__ __launch_bounds__(64) void k_decode_run(DecState *D)
         const dgu8 *w = (const dgu8 *)D->words + i * 8;
         lds.wtab[i] = (uint32_t)w[0] | ((uint32_t)w[1] << 8) | ((uint32_t)w[2] << 16) | ((uint32_t)w[3] << 24);
     }
+    {   // p_lit image (u16[65536], 128 KiB) HBM -> LDS, 16 bytes per lane and step
+        typedef uint32_t __attribute__((ext_vector_type(4))) v4u;
+        const __attribute__((address_space(1))) v4u *src = (const __attribute__((address_space(1))) v4u *)D->p_lit;
+        v4u *dst = (v4u *)lds.plit;
+        for (uint32_t i = c.lane; i < 65536 * 2 / 16; i += 64) dst[i] = src[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     const uint32_t max = D->raw_blocksize;
     Ck k;
     bool done = false;
@@ -484,8 +687,8 @@ __global__ __launch_bounds__(64) void k_decode_run(DecState *D)
                 ck_take(c, k);
                 uint32_t ni = i + 1, byte = 0, runlen = 0;
                 if (type == DT_BAD) byte = ddirect16(c, 8);
-                else if (type == DT_ENTROPY) { byte = dbyte_tree(c, c.ctx * 256); c.ctx = byte; }
-                else if (dbit(c, 0, 0, P_RLE_FLAG) == 0) byte = dbyte_tree(c, 65536 + sctx * 256);   // p_delta follows p_lit
+                else if (type == DT_ENTROPY) { byte = dbyte_tree_l(c, c.ctx * 256); c.ctx = byte; }
+                else if (dbit(c, P_RLE_FLAG) == 0) byte = dbyte_tree_g(c, sctx * 256);
                 else { runlen = dmatchlen_2(c) + 11; if (i == 0) c.err = 2; }
                 if (c.need) { ck_rollback(c, k); break; }
                 if (c.err) { c.status = c.err == 2 ? DEC_ERR_MINUS1 : DEC_ERR_DECODE; break; }
@@ -507,10 +710,12 @@ __global__ __launch_bounds__(64) void k_decode_run(DecState *D)
         } break;
         case DEC_PH_POST: {
             const uint32_t type = c.type, size = c.out_size;
+            DTM_DECL;
             if (type == DT_EXE) dinverse_e89(c, size);
             else if (type == DT_ENGTXT) dinverse_dict(c, size);
             else if (type >= DT_DLT) { dinverse_delta(c, size, kDltIndexD[type - DT_DLT]); dcopy2dict(c, size); }
             else if (type == DT_BAD || type == DT_ENTROPY) dcopy2dict(c, size);
+            DTM_ADD(c, 4);
             c.phase = DEC_PH_TAIL;
         } break;
         case DEC_PH_TAIL: {
@@ -528,7 +733,17 @@ __global__ __launch_bounds__(64) void k_decode_run(DecState *D)
         }
     }
     // store the stream state
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     for (uint32_t i = c.lane; i < P_COUNT; i += 64) D->probs[i] = lds.P[i];
+    {
+        typedef uint32_t __attribute__((ext_vector_type(4))) v4u;
+        __attribute__((address_space(1))) v4u *dst = (__attribute__((address_space(1))) v4u *)D->p_lit;
+        const v4u *src = (const v4u *)lds.plit;
+        for (uint32_t i = c.lane; i < 65536 * 2 / 16; i += 64) dst[i] = src[i];
+    }
+#ifdef CSCMI_TIMERS
+    if (c.lane == 0) { for (int i = 0; i < 16; i++) D->dbg[i] += c.tm[i]; D->dbg[7] += __builtin_readcyclecounter() - tk0; D->dbg[15]++; }
+#endif
     if (c.lane == 0) {
         for (int i = 0; i < 2; i++) { D->taken[i] = c.taken[i]; D->rd[i] = c.rd[i]; D->fill[i] = c.fill[i]; }
         D->range = c.range; D->code = c.code; D->bc_bits = c.bc_bits; D->bc_val = c.bc_val;
@@ -540,14 +755,47 @@ __global__ __launch_bounds__(64) void k_decode_run(DecState *D)
     }
 }
 
+extern __shared__ __attribute__((aligned(16))) uint8_t dec_smem[];
+
+// one stream: CSCDec_Decode
+__global__ __launch_bounds__(64) void k_decode_run(DecState *D)
+{
+    decode_stream((gDecState *)D, *(DecLds *)dec_smem);
+}
+// many independent streams (the tasks of an archive): workgroup b advances stream b until it needs input or its
+// Decompress call is complete; one stream per CU (the literal table fills most of the LDS)
+__global__ __launch_bounds__(64) void k_decode_run_multi(DecState *const *states)
+{
+    // the pointer is the same in every lane; say so, or everything loaded through it is treated as per-lane data
+    const uint64_t a = (uint64_t)states[blockIdx.x];
+    const uint64_t u = ((uint64_t)DUNI((uint32_t)(a >> 32)) << 32) | DUNI((uint32_t)a);
+    decode_stream((gDecState *)u, *(DecLds *)dec_smem);
+}
+
 __global__ void k_decode_init(DecState *D)
 {
     uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
-    for (uint32_t i = tid; i < 256 * 256; i += nth) D->p_lit[i] = 2048;
+    for (uint32_t i = tid; i < 256 * 256 / 2; i += nth) D->p_lit[i] = 2048u | (2048u << 16);   // u16 image of p_lit
     for (uint32_t i = tid; i < P_COUNT; i += nth) D->probs[i] = 2048;
 }
 
+static hipError_t dec_lds_attr()
+{
+    static hipError_t e1 = hipFuncSetAttribute((const void *)k_decode_run, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLdsBytes);
+    static hipError_t e2 = hipFuncSetAttribute((const void *)k_decode_run_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLdsBytes);
+    return e1 != hipSuccess ? e1 : e2;
+}
+
 void launch_decode_init(DecState *D, hipStream_t st) { hipLaunchKernelGGL(k_decode_init, dim3(64), dim3(256), 0, st, D); }
-void launch_decode_run(DecState *D, hipStream_t st) { hipLaunchKernelGGL(k_decode_run, dim3(1), dim3(64), 0, st, D); }
+void launch_decode_run(DecState *D, hipStream_t st)
+{
+    (void)dec_lds_attr();
+    hipLaunchKernelGGL(k_decode_run, dim3(1), dim3(64), kDecLdsBytes, st, D);
+}
+void launch_decode_run_multi(DecState *const *states, uint32_t n, hipStream_t st)
+{
+    (void)dec_lds_attr();
+    hipLaunchKernelGGL(k_decode_run_multi, dim3(n), dim3(64), kDecLdsBytes, st, states);
+}
 
 }  // namespace cscmi

@@ -139,6 +139,7 @@ struct DecState {
     uint32_t status, out_size;
     uint64_t consumed;
     uint32_t probs[P_COUNT + 4];
+    uint64_t dbg[16];          // development-only section timers (-DCSCMI_TIMERS builds); zero otherwise
 };
 
 }  // namespace cscmi

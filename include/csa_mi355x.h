@@ -37,14 +37,14 @@ typedef struct CSAOptions {
     int recurse;            /* -r                                               csarc.cpp:169-170 */
     int overwrite;          /* -f                                               csarc.cpp:171-172 */
     int verbose;            /* -v (List: report fragments)                      csarc.cpp:173-174 */
-    int mt_count;           /* -t#  Extract/Test: concurrent task decoders (1..64 here; the reference
-                               clamps to 8).  Add: ignored -- the archive is always laid out as the
-                               reference's single-worker run lays it out (task-id order).          */
+    int mt_count;           /* -t#  accepted for parity with the reference and otherwise unused: Add always
+                               writes the single-worker (task-id order) layout, Extract/Test decode
+                               `device_streams` tasks per kernel launch                                  */
     int split_count;        /* -p##  single-file split, default 1               csarc.cpp:190-191 */
     const char *to_dir;     /* -o dir, default "./"                             csarc.cpp:147,183-189 */
     /* --- not in the reference --- */
-    int device_streams;     /* Add: how many task streams advance per kernel launch; 0 = as many as
-                               fit the HBM budget (at most 1024)                                     */
+    int device_streams;     /* task streams advanced per kernel launch; 0 = as many as fit the HBM budget,
+                               at most 1024 (Add) / 256 = one per CU (Extract, Test)                    */
     uint64_t hbm_budget;    /* Add: bytes of HBM the concurrent task encoders may use; 0 = 3/4 of
                                the free device memory                                                */
     uint64_t task_bytes;    /* Add: 0 = the reference's task split (archive identical to csarc's).

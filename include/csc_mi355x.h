@@ -97,6 +97,10 @@ int CSCMI_EncodeDeviceChunk(CSCEncHandle p, const void *device_ptr, size_t size)
 /* n independent handles (tasks of a -p / per-extension split) advanced by one chunk each with ONE kernel
  * launch, one workgroup per stream; handles must live on the current device.  sizes[i] == 0 skips handle i. */
 int CSCMI_EncodeDeviceChunkBatch(int n, CSCEncHandle *hs, const void *const *device_ptrs, const size_t *sizes);
+/* CSCDec_Decode for n independent handles at once: one kernel launch per round advances every stream (one
+ * workgroup each); block reads and Write calls happen on the calling thread, per stream in the order CSCDec_Decode
+ * would make them.  rcs[i] = what CSCDec_Decode(hs[i], oss[i], NULL) would return.  Returns 0 or CSCMI_DEVICE_ERROR. */
+int CSCMI_DecodeBatch(int n, CSCDecHandle *hs, ISeqOutStream *const *oss, int *rcs);
 /* Host-memory variant used by CSCEnc_Encode itself. */
 int CSCMI_EncodeHostChunk(CSCEncHandle p, const void *host_ptr, size_t size);
 void CSCMI_GetStats(CSCEncHandle p, CSCMIStats *out);

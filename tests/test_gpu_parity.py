@@ -261,3 +261,53 @@ def test_golden_streams_decode_on_device(prod, orc, zalloc):
         name = key.split("/m")[0]
         data = cases.build(cases.STREAM_CASES[name][0])
         assert prod.decode(bytes.fromhex(want["stream_hex"])) == (0, data), key
+
+
+def test_batch_decode_equals_one_by_one(prod, orc, zalloc):
+    """CSCMI_DecodeBatch: many handles advanced by one launch per round; per stream the same bytes, the same return
+    code and the same Read sizes as CSCDec_Decode alone -- including a damaged and a truncated stream in the batch"""
+    import ctypes as C
+    from csc_amd.capi import BytesReader, BytesWriter, CSC_PROP_SIZE
+    L = prod.lib
+    L.CSCMI_DecodeBatch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    L.CSCMI_DecodeBatch.restype = C.c_int
+    names = ["mix_types", "text_300k", "exe_300k", "delta_200k", "entropy8_100k", "zeros_8k", "one_byte", "empty",
+             "window_wrap_32k", "dup_blocks", "random_64k", "abcdefgh_64k"]
+    streams = []
+    for i, n in enumerate(names):
+        spec, dict_size, clamp, max_read = cases.STREAM_CASES[n]
+        data = cases.build(spec)
+        rc, s = orc.encode(data, (3, 2, 5, 1)[i % 4], dict_size, alloc=zalloc, clamp_dict=clamp, max_read=max_read)
+        assert rc == 0
+        streams.append(s)
+    bad = bytearray(streams[0]); bad[len(bad) // 2] ^= 0x10
+    streams.append(bytes(bad))                      # damaged
+    streams.append(streams[1][:len(streams[1]) // 2])   # truncated
+    want = [orc.decode(s, alloc=zalloc) for s in streams]
+    alone = []
+    for s in streams:
+        r = BytesReader(s[CSC_PROP_SIZE:])
+        alone.append((prod.decode(s), None))
+    readers, writers, hs = [], [], []
+    for s in streams:
+        props = prod.read_properties(s[:CSC_PROP_SIZE])
+        r = BytesReader(s[CSC_PROP_SIZE:]); w = BytesWriter()
+        h = L.CSCDec_Create(C.byref(props), C.cast(r.ptr(), C.c_void_p), None)
+        assert h
+        readers.append(r); writers.append(w); hs.append(h)
+    n = len(hs)
+    H = (C.c_void_p * n)(*hs)
+    W = (C.c_void_p * n)(*[C.cast(w.ptr(), C.c_void_p) for w in writers])
+    R = (C.c_int * n)()
+    assert L.CSCMI_DecodeBatch(n, H, W, R) == 0
+    for h in hs:
+        L.CSCDec_Destroy(h)
+    for i in range(n):
+        assert (R[i], bytes(writers[i].out)) == want[i] == alone[i][0], i
+        # the caller saw exactly the reads a lone CSCDec_Decode makes
+        r1 = BytesReader(streams[i][CSC_PROP_SIZE:])
+        props = prod.read_properties(streams[i][:CSC_PROP_SIZE])
+        h = L.CSCDec_Create(C.byref(props), C.cast(r1.ptr(), C.c_void_p), None)
+        L.CSCDec_Decode(h, C.cast(BytesWriter().ptr(), C.c_void_p), None)
+        L.CSCDec_Destroy(h)
+        assert readers[i].calls == r1.calls, i
