@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "../../include/csc_mi355x.h"
@@ -48,8 +49,81 @@ const char kWords[122][8] = {   // csc_filters.cpp:8-38; symbol 0x82+i expands t
     "that","said","with","have","this","from","were","tion",
 };
 
+// A decoder's device state is ONE allocation (zero-filled on every use) and its pinned staging ONE allocation;
+// both, and the HIP stream, are recycled through a per-process cache keyed by (device, sizes): an archive reader
+// creates one decoder per task.
+struct DecRes {
+    int device;
+    size_t dsize, hsize;
+    uint8_t *dslab, *hslab;
+    hipStream_t stream;
+};
+std::mutex g_dec_mu;
+std::vector<DecRes *> g_dec_cache;
+size_t g_dec_cache_bytes = 0;
+constexpr size_t kDecCacheMaxBytes = 32ull << 30;
+
+void dec_res_destroy(DecRes *r)
+{
+    if (!r) return;
+    if (r->dslab) (void)hipFree(r->dslab);
+    if (r->hslab) (void)hipHostFree(r->hslab);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+}
+void dec_cache_trim()
+{
+    std::vector<DecRes *> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_dec_mu);
+        drop.swap(g_dec_cache);
+        g_dec_cache_bytes = 0;
+    }
+    for (DecRes *r : drop) dec_res_destroy(r);
+}
+DecRes *dec_res_get(int device, size_t dsize, size_t hsize)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_dec_mu);
+        for (size_t i = 0; i < g_dec_cache.size(); i++) {
+            DecRes *r = g_dec_cache[i];
+            if (r->device == device && r->dsize == dsize && r->hsize == hsize) {
+                g_dec_cache.erase(g_dec_cache.begin() + i);
+                g_dec_cache_bytes -= dsize;
+                return r;
+            }
+        }
+    }
+    DecRes *r = new DecRes();
+    memset(r, 0, sizeof(*r));
+    r->device = device; r->dsize = dsize; r->hsize = hsize;
+    bool ok = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) == hipSuccess;
+    if (ok && hipMalloc((void **)&r->dslab, dsize) != hipSuccess) {
+        (void)hipGetLastError();
+        dec_cache_trim();                                  // give cached slabs back and try once more
+        ok = hipMalloc((void **)&r->dslab, dsize) == hipSuccess;
+    }
+    ok = ok && hipHostMalloc((void **)&r->hslab, hsize, hipHostMallocDefault) == hipSuccess;
+    if (!ok) { dec_res_destroy(r); return nullptr; }
+    return r;
+}
+void dec_res_put(DecRes *r)
+{
+    if (!r) return;
+    {
+        std::lock_guard<std::mutex> lk(g_dec_mu);
+        if (g_dec_cache_bytes + r->dsize <= kDecCacheMaxBytes && g_dec_cache.size() < 1024) {
+            g_dec_cache.push_back(r);
+            g_dec_cache_bytes += r->dsize;
+            return;
+        }
+    }
+    dec_res_destroy(r);
+}
+
 struct DecInstance {
     uint32_t magic;
+    DecRes *res;
     ISzAlloc *alloc;
     ISeqInStream *is;
     int device;
@@ -67,13 +141,8 @@ struct DecInstance {
 void free_all(DecInstance *x)
 {
     (void)hipSetDevice(x->device);
-    auto F = [](void *p) { if (p) (void)hipFree(p); };
-    F(x->h.wnd); F(x->h.p_lit); F(x->h.out); F(x->h.swap); F(x->h.q[0]); F(x->h.q[1]);
-    F(x->h.qsize[0]); F(x->h.qsize[1]); F(x->h.undo_addr); F(x->h.undo_val); F((void *)x->h.words); F(x->d_state);
-    auto H = [](void *p) { if (p) (void)hipHostFree(p); };
-    H(x->h_read); H(x->h_block); H(x->h_out);
+    if (x->res) { (void)hipStreamSynchronize(x->res->stream); dec_res_put(x->res); }
     free(x->h_qsize[0]); free(x->h_qsize[1]);
-    if (x->stream) (void)hipStreamDestroy(x->stream);
     x->magic = 0;
     ISzAlloc *a = x->alloc;
     a->Free(a, x);
@@ -143,13 +212,6 @@ int decompress(DecInstance *x, uint32_t *size)
     }
 }
 
-template <typename T>
-bool dalloc(T **p, size_t bytes)
-{
-    if (hipMalloc((void **)p, bytes) != hipSuccess) { *p = nullptr; return false; }
-    return hipMemset(*p, 0, bytes) == hipSuccess;
-}
-
 }  // namespace
 
 extern "C" {
@@ -174,27 +236,38 @@ CSCDecHandle CSCDec_Create(const CSCProps *props, ISeqInStream *instream, ISzAll
     DecState &h = x->h;
     h.wnd_size = (uint32_t)props->dict_size; h.bsize = props->csc_blocksize; h.raw_blocksize = props->raw_blocksize;
     h.qslots = 2 * (props->raw_blocksize / props->csc_blocksize + 1) + 16;
-    bool ok = hipGetDevice(&x->device) == hipSuccess && hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && dalloc(&h.wnd, (size_t)h.wnd_size + 256);
-    ok = ok && dalloc(&h.p_lit, 2 * 65536 * sizeof(uint32_t));
-    ok = ok && dalloc(&h.out, (size_t)h.raw_blocksize + 256) && dalloc(&h.swap, 2 * (size_t)h.raw_blocksize + 256);
-    ok = ok && dalloc(&h.q[0], (size_t)h.qslots * h.bsize + 256) && dalloc(&h.q[1], (size_t)h.qslots * h.bsize + 256);
-    ok = ok && dalloc(&h.qsize[0], sizeof(uint32_t) * h.qslots) && dalloc(&h.qsize[1], sizeof(uint32_t) * h.qslots);
-    ok = ok && dalloc(&h.undo_addr, sizeof(uint32_t) * kDecUndoCap) && dalloc(&h.undo_val, sizeof(uint32_t) * kDecUndoCap);
-    uint8_t *dwords = nullptr;
-    ok = ok && dalloc(&dwords, sizeof(kWords)) && hipMemcpy(dwords, kWords, sizeof(kWords), hipMemcpyHostToDevice) == hipSuccess;
-    h.words = dwords;
-    ok = ok && dalloc(&x->d_state, sizeof(DecState));
-    ok = ok && hipHostMalloc((void **)&x->h_read, sizeof(DecState), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&x->h_block, h.bsize, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&x->h_out, h.raw_blocksize, hipHostMallocDefault) == hipSuccess;
+    bool ok = hipGetDevice(&x->device) == hipSuccess;
+    // one device slab (zero-filled) and one pinned slab
+    size_t doff = 0, hoff = 0;
+    auto dtake = [&](size_t bytes) { size_t o = doff; doff += (bytes + 255) & ~(size_t)255; return o; };
+    auto htake = [&](size_t bytes) { size_t o = hoff; hoff += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_wnd = dtake((size_t)h.wnd_size + 256), o_plit = dtake(2 * 65536 * sizeof(uint32_t));
+    const size_t o_out = dtake((size_t)h.raw_blocksize + 256), o_swap = dtake(2 * (size_t)h.raw_blocksize + 256);
+    const size_t o_q0 = dtake((size_t)h.qslots * h.bsize + 256), o_q1 = dtake((size_t)h.qslots * h.bsize + 256);
+    const size_t o_qs0 = dtake(sizeof(uint32_t) * h.qslots), o_qs1 = dtake(sizeof(uint32_t) * h.qslots);
+    const size_t o_ua = dtake(sizeof(uint32_t) * kDecUndoCap), o_uv = dtake(sizeof(uint32_t) * kDecUndoCap);
+    const size_t o_words = dtake(sizeof(kWords)), o_state = dtake(sizeof(DecState));
+    const size_t p_read = htake(sizeof(DecState)), p_block = htake(h.bsize), p_out = htake(h.raw_blocksize);
+    if (ok) { x->res = dec_res_get(x->device, doff, hoff); ok = x->res != nullptr; }
+    if (ok) {
+        uint8_t *D = x->res->dslab, *H = x->res->hslab;
+        x->stream = x->res->stream;
+        h.wnd = D + o_wnd; h.p_lit = (uint32_t *)(D + o_plit); h.out = D + o_out; h.swap = D + o_swap;
+        h.q[0] = D + o_q0; h.q[1] = D + o_q1; h.qsize[0] = (uint32_t *)(D + o_qs0); h.qsize[1] = (uint32_t *)(D + o_qs1);
+        h.undo_addr = (uint32_t *)(D + o_ua); h.undo_val = (uint32_t *)(D + o_uv);
+        h.words = D + o_words;
+        x->d_state = (DecState *)(D + o_state);
+        x->h_read = (DecState *)(H + p_read); x->h_block = H + p_block; x->h_out = H + p_out;
+        ok = hipMemsetAsync(D, 0, doff, x->stream) == hipSuccess
+          && hipMemcpyAsync(D + o_words, kWords, sizeof(kWords), hipMemcpyHostToDevice, x->stream) == hipSuccess;
+    }
     x->h_qsize[0] = (uint32_t *)calloc(h.qslots, sizeof(uint32_t));
     x->h_qsize[1] = (uint32_t *)calloc(h.qslots, sizeof(uint32_t));
     ok = ok && x->h_qsize[0] && x->h_qsize[1];
     if (ok) {
         h.p_delta = h.p_lit + 65536;
         h.phase = DEC_PH_PRIME0;
-        ok = hipMemcpy(x->d_state, &h, sizeof(DecState), hipMemcpyHostToDevice) == hipSuccess;
+        ok = hipMemcpyAsync(x->d_state, &h, sizeof(DecState), hipMemcpyHostToDevice, x->stream) == hipSuccess;
         if (ok) {
             launch_decode_init(x->d_state, x->stream);
             ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(x->stream) == hipSuccess;

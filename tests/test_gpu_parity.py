@@ -282,32 +282,36 @@ def test_batch_decode_equals_one_by_one(prod, orc, zalloc):
         streams.append(s)
     bad = bytearray(streams[0]); bad[len(bad) // 2] ^= 0x10
     streams.append(bytes(bad))                      # damaged
-    streams.append(streams[1][:len(streams[1]) // 2])   # truncated
+    streams.append(streams[1][:len(streams[1]) // 2])   # truncated inside the first block
+    streams.append(streams[8][:len(streams[8]) - 40000])   # truncated later
     want = [orc.decode(s, alloc=zalloc) for s in streams]
     alone = []
     for s in streams:
         r = BytesReader(s[CSC_PROP_SIZE:])
         alone.append((prod.decode(s), None))
-    readers, writers, hs = [], [], []
-    for s in streams:
+    readers, writers, hs, idx = [], [], [], []
+    for i, s in enumerate(streams):
         props = prod.read_properties(s[:CSC_PROP_SIZE])
         r = BytesReader(s[CSC_PROP_SIZE:]); w = BytesWriter()
         h = L.CSCDec_Create(C.byref(props), C.cast(r.ptr(), C.c_void_p), None)
-        assert h
-        readers.append(r); writers.append(w); hs.append(h)
+        if not h:                                   # Create already reads two blocks: a stream cut inside them never opens
+            assert want[i][0] is None and alone[i][0][0] is None, i
+            continue
+        readers.append(r); writers.append(w); hs.append(h); idx.append(i)
     n = len(hs)
+    assert n >= len(names) + 1
     H = (C.c_void_p * n)(*hs)
     W = (C.c_void_p * n)(*[C.cast(w.ptr(), C.c_void_p) for w in writers])
     R = (C.c_int * n)()
     assert L.CSCMI_DecodeBatch(n, H, W, R) == 0
     for h in hs:
         L.CSCDec_Destroy(h)
-    for i in range(n):
-        assert (R[i], bytes(writers[i].out)) == want[i] == alone[i][0], i
+    for k, i in enumerate(idx):
+        assert (R[k], bytes(writers[k].out)) == want[i] == alone[i][0], i
         # the caller saw exactly the reads a lone CSCDec_Decode makes
         r1 = BytesReader(streams[i][CSC_PROP_SIZE:])
         props = prod.read_properties(streams[i][:CSC_PROP_SIZE])
         h = L.CSCDec_Create(C.byref(props), C.cast(r1.ptr(), C.c_void_p), None)
         L.CSCDec_Decode(h, C.cast(BytesWriter().ptr(), C.c_void_p), None)
         L.CSCDec_Destroy(h)
-        assert readers[i].calls == r1.calls, i
+        assert readers[k].calls == r1.calls, i
