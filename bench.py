@@ -73,6 +73,43 @@ def cpu_baseline(data, level, dict_size, task_size, sample_bytes):
             "seconds": round(dt, 2), "ratio": round(len(stream) / max(1, len(sample)), 4)}, stream
 
 
+def decode_all(lib, streams, whole, slices, width=256):
+    """decode every task stream with CSCMI_DecodeBatch (waves of `width` handles) and compare with the input"""
+    import numpy as np
+    import torch
+    from csc_amd.capi import BytesReader, BytesWriter, CSC_PROP_SIZE
+    L = lib.lib
+    L.CSCMI_DecodeBatch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    L.CSCMI_DecodeBatch.restype = C.c_int
+    host = whole.cpu().numpy()
+    ok, total = True, 0
+    t0 = time.perf_counter()
+    for a in range(0, len(streams), width):
+        part = streams[a:a + width]
+        rs, ws, hs = [], [], []
+        for s in part:
+            props = lib.read_properties(s[:CSC_PROP_SIZE])
+            r = BytesReader(s[CSC_PROP_SIZE:]); w = BytesWriter()
+            h = L.CSCDec_Create(C.byref(props), C.cast(r.ptr(), C.c_void_p), None)
+            if not h:
+                return {"error": "CSCDec_Create failed"}
+            rs.append(r); ws.append(w); hs.append(h)
+        n = len(hs)
+        R = (C.c_int * n)()
+        rc = L.CSCMI_DecodeBatch(n, (C.c_void_p * n)(*hs), (C.c_void_p * n)(*[C.cast(w.ptr(), C.c_void_p) for w in ws]), R)
+        for h in hs:
+            L.CSCDec_Destroy(h)
+        if rc != 0 or any(R[i] != 0 for i in range(n)):
+            return {"error": f"batch decode failed rc={rc}"}
+        for i, w in enumerate(ws):
+            off, size = slices[a + i]
+            total += len(w.out)
+            ok = ok and len(w.out) == size and bool(np.array_equal(np.frombuffer(w.out, dtype=np.uint8), host[off:off + size]))
+    dt = time.perf_counter() - t0
+    return {"value": round(total / 1e6 / dt, 3), "unit": "MB/s", "seconds": round(dt, 2), "roundtrip_ok": ok,
+            "what": f"the same task streams decoded by CSCMI_DecodeBatch, {min(width, len(streams))} per launch, incl. compare"}
+
+
 def multi_stream_job(lib, stream_counts, level, dict_size):
     """Secondary measurement (extra `multi_stream` field of the JSON line, never `value`): the archiver's
     task split is where this path shards, so one GPU can run every task of `csarc a -m3 -d64m -p<S>` at
@@ -121,11 +158,13 @@ def multi_stream_job(lib, stream_counts, level, dict_size):
         digest = hashlib.sha256(b"".join(hashlib.sha256(bytes(w.out)).digest() for w in ws)).hexdigest()
         for h in hs:
             L.CSCEnc_Destroy(h)
+        # and back: every task stream through the HIP decoder, 256 streams per launch (one per CU), checked byte for byte
+        dec = decode_all(lib, [bytes(w.out) for w in ws], whole, slices)
         balg = ALG_BYTES.get(level, 42.0) + out / total
         results.append({"what": f"whole enwik9 stand-in (10^9 B) as csarc -m{level} -d64m -p{S}: {S} independent task streams, one workgroup each, 1 GPU",
                         "value": round(total / 1e6 / dt, 3), "unit": "MB/s", "seconds": round(dt, 2), "ratio": round(out / total, 4),
                         "streams": S, "batch_launches": k, "hbm_roofline_frac": round(balg * total / dt / 1e9 / HBM_PEAK_GBS, 8),
-                        "sha256_of_stream_sha256s": digest})
+                        "sha256_of_stream_sha256s": digest, "decode": dec})
     return {"multi_stream": results}
 
 
