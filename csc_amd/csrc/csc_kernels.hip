@@ -190,10 +190,11 @@ DEV void rc_shift_low(Sc &c)
 // arithmetic half of EncodeBit (csc_coder.h:67-81); p is the probability BEFORE its update
 DEV void rc_code(Sc &c, uint32_t v, uint32_t p)
 {
-    uint32_t bound = (c.rc_range >> 12) * p;
-    if (v) c.rc_range = bound;
-    else { c.rc_low += bound; c.rc_range -= bound; }
-    if (c.rc_range < (1u << 24)) { c.rc_range <<= 8; rc_shift_low(c); }
+    // selects, not branches: a taken scalar branch costs a lone wavefront ~35 cycles (tools/ub/ub_issue.hip)
+    const uint32_t bound = (c.rc_range >> 12) * p;
+    c.rc_low += v ? 0u : bound;
+    c.rc_range = v ? bound : c.rc_range - bound;
+    if (__builtin_expect(c.rc_range < (1u << 24), 0)) { c.rc_range <<= 8; rc_shift_low(c); }
 }
 DEV uint32_t p_update(uint32_t v, uint32_t p) { return v ? p + ((0xFFFu - p) >> 5) : p - (p >> 5); }
 
@@ -328,6 +329,62 @@ DEV uint32_t literal_price(const Sc &c, uint32_t fstate, uint32_t fctx, uint32_t
     return UNI(pr) + lds_price(c, 0, P_STATE + fstate * 3);
 }
 
+// ------------------------------------------------------------------------------------------
+// A packet's binary decisions under the small (LDS) tables are all known before the first one is coded, and --
+// lengths below 143 -- no probability is used twice inside one packet.  So they are laid out one per lane
+// (decision k in lane k: table index, bit), fetched with ONE LDS gather, updated by one vector operation and
+// stored with one scatter; only the range arithmetic stays serial, fed from registers.  The order of the
+// decisions, and where the direct bits of a distance fall between them, is the reference's.
+struct Decisions {
+    uint32_t idx, bit;   // per lane
+    uint32_t n;          // uniform: decisions so far
+};
+DEV void dec_one(const Sc &c, Decisions &d, uint32_t idx, uint32_t bit)
+{
+    d.idx = wrlane(idx, d.n, d.idx);
+    d.bit = wrlane(bit, d.n, d.bit);
+    d.n++;
+}
+// the nb decisions of an MSB-first binary tree walk of the nb-bit value x; node numbering 1, 2|b, 4|bb, ...; table index = base + node
+DEV void dec_tree(const Sc &c, Decisions &d, uint32_t base, uint32_t x, uint32_t nb)
+{
+    const uint32_t j = c.lane - d.n;                 // level of this lane (wraps for lanes below d.n)
+    const bool in = j < nb;
+    const uint32_t node = (1u << (j & 31u)) | (x >> ((nb - j) & 31u));
+    const uint32_t b = (x >> ((nb - 1u - j) & 31u)) & 1u;
+    d.idx = in ? base + node : d.idx;
+    d.bit = in ? b : d.bit;
+    d.n += nb;
+}
+// encode_matchlen_1 (csc_model.cpp:113-145) as decisions; len < 143 + 1
+DEV void dec_matchlen_1(const Sc &c, Decisions &d, uint32_t len)
+{
+    if (len < 8) { dec_one(c, d, P_LEN_SLOT, 0); dec_tree(c, d, P_LEN_X1, len, 3); }
+    else if (len < 16) { dec_one(c, d, P_LEN_SLOT, 1); dec_one(c, d, P_LEN_SLOT + 1, 0); dec_tree(c, d, P_LEN_X2, len - 8, 3); }
+    else { dec_one(c, d, P_LEN_SLOT, 1); dec_one(c, d, P_LEN_SLOT + 1, 1); dec_tree(c, d, P_LEN_X3, len - 16, 7); }
+}
+// gather + update + scatter; returns the probabilities as they were
+DEV uint32_t dec_apply(Sc &c, const Decisions &d)
+{
+    uint32_t p = 0;
+    if (c.lane < d.n) { p = c.L->P[d.idx]; c.L->P[d.idx] = p_update(d.bit, p); }
+    return p;
+}
+// range-code decisions [0, to) from registers (static lane numbers), and the four of a distance's low-bits tree
+DEV void dec_code(Sc &c, uint32_t pold, uint64_t bits, uint32_t to)
+{
+#pragma unroll
+    for (uint32_t k = 0; k < 24; k++) {
+        if (k >= to) break;
+        rc_code(c, (uint32_t)(bits >> k) & 1u, rdlane(pold, k));
+    }
+}
+DEV void dec_code4(Sc &c, uint32_t pold, uint64_t bits, uint32_t from)
+{
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) rc_code(c, (uint32_t)(bits >> (from + k)) & 1u, rdlane(pold, from + k));
+}
+
 // Model::EncodeRep0Len1, csc_model.cpp:198-207
 DEV void encode_rep0len1(Sc &c)
 {
@@ -344,7 +401,21 @@ DEV uint32_t rep0len1_price(const Sc &c, uint32_t fs)   // csc_model.cpp:209-216
 }
 
 // Model::EncodeRepDistMatch, csc_model.cpp:218-232
+DEV void encode_rep_match_seq(Sc &c, uint32_t rep_idx, uint32_t match_len);
 DEV void encode_rep_match(Sc &c, uint32_t rep_idx, uint32_t match_len)
+{
+    if (__builtin_expect(match_len >= 143, 0)) { encode_rep_match_seq(c, rep_idx, match_len); return; }
+    Decisions d; d.idx = 0; d.bit = 0; d.n = 0;
+    const uint32_t s3 = c.state * 3;
+    dec_one(c, d, P_STATE + s3, 1); dec_one(c, d, P_STATE + s3 + 1, 0); dec_one(c, d, P_STATE + s3 + 2, 1);
+    dec_tree(c, d, P_REPDIST + s3 - 1, rep_idx, 2);
+    dec_matchlen_1(c, d, match_len);
+    const uint32_t pold = dec_apply(c, d);
+    dec_code(c, pold, __ballot(d.bit != 0), d.n);
+    c.state = (c.state * 4 + 3) & 0x3F;
+    c.st_match++;
+}
+DEV void encode_rep_match_seq(Sc &c, uint32_t rep_idx, uint32_t match_len)
 {
     enc_bit_lds(c, 1, P_STATE + c.state * 3 + 0);
     enc_bit_lds(c, 0, P_STATE + c.state * 3 + 1);
@@ -370,7 +441,39 @@ DEV uint32_t rep_dist_price(const Sc &c, uint32_t fs, uint32_t rep_idx)   // csc
 DEV uint32_t dist_slot(uint32_t dist) { return dist < 3 ? dist : 33u - (uint32_t)__builtin_clz(dist - 1); }
 
 // Model::EncodeMatch, csc_model.cpp:301-366
+DEV void encode_match_seq(Sc &c, uint32_t dist, uint32_t len);
 DEV void encode_match(Sc &c, uint32_t dist, uint32_t len)
+{
+    if (__builtin_expect(len >= 143, 0)) { encode_match_seq(c, dist, len); return; }
+    Decisions d; d.idx = 0; d.bit = 0; d.n = 0;
+    const uint32_t s3 = c.state * 3;
+    dec_one(c, d, P_STATE + s3, 1); dec_one(c, d, P_STATE + s3 + 1, 1);
+    dec_matchlen_1(c, d, len);
+    uint32_t pdist_pos, sbits;
+    if (len == 0) { pdist_pos = 0; sbits = 3; }
+    else if (len <= 2) { pdist_pos = 16 * (len - 1) + 8; sbits = 4; }
+    else if (len <= 5) { pdist_pos = 32 * (len - 3) + 8 + 16 * 2; sbits = 5; }
+    else { pdist_pos = 32 * 3 + 8 + 16 * 2; sbits = 5; }
+    const uint32_t slot = dist_slot(dist);
+    const uint32_t extra_bits = slot > 2 ? slot - 2 : 0;
+    dec_tree(c, d, P_DIST + pdist_pos, slot, sbits);
+    const uint32_t n_head = d.n;                       // the distance's direct bits go between these and the low-bits tree
+    uint32_t extra_len = 0;
+    if (extra_bits) {
+        extra_len = dist - (1u << extra_bits) - 1;
+        dec_tree(c, d, P_DIST_EXTRA + (extra_bits - 1) * 16, __brev(extra_len & 0x0Fu) >> 28, 4);   // rev16_table_, csc_model.cpp:57-62
+    }
+    const uint32_t pold = dec_apply(c, d);
+    const uint64_t bits = __ballot(d.bit != 0);
+    dec_code(c, pold, bits, n_head);
+    if (extra_bits) {
+        if (extra_bits > 4) enc_direct(c, extra_len >> 4, extra_bits - 4);
+        dec_code4(c, pold, bits, n_head);
+    }
+    c.state = (c.state * 4 + 1) & 0x3F;
+    c.st_match++;
+}
+DEV void encode_match_seq(Sc &c, uint32_t dist, uint32_t len)
 {
     enc_bit_lds(c, 1, P_STATE + c.state * 3 + 0);
     enc_bit_lds(c, 1, P_STATE + c.state * 3 + 1);

@@ -28,7 +28,7 @@ st = St(); lib.lib.CSCMI_GetStats.argtypes = [C.c_void_p, C.c_void_p]; lib.lib.C
 lib.lib.CSCMI_DebugTimers.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 tm = (C.c_uint64 * 16)(); lib.lib.CSCMI_DebugTimers(h, tm)
 names = ["fm:hash+gather", "fm:slots+extend", "fm:replay+insert", "pricing", "dp:statefix", "dp:litprice+relax", "dp:exit(backward+encode+slide)",
-         "slide_pos", "dict filter", "window memcpy", "-", "-", "-", "-", "-", "-"]
+         "slide_pos", "dict filter", "window memcpy", "lazy: symbol coding", "lazy: FindMatch pick", "-", "-", "-", "-"]
 tot = sum(tm)
 print(f"level {level}: {len(data)/1e6/dt:.3f} MB/s, kernel {st.encode_kernel_ms:.0f} ms, find_match {st.find}, slide {st.slide}, lit {st.lit}, match {st.match}")
 for n, v in zip(names, tm):
