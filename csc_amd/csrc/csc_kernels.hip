@@ -46,6 +46,7 @@ __device__ static const uint32_t kDltIndex[5] = {1, 2, 3, 4, 8};   // csc_typede
 
 // ------------------------------------------------------------------------------------------
 // LDS image of one stream while k_encode_runs is resident (< 40 KiB: four streams per CU fit in 160 KiB)
+constexpr uint32_t kTokRing = 2048;
 struct EncLds {
     uint32_t P[P_COUNT + 4];                  // small adaptive probability tables
     uint32_t p2b[512];                        // probability -> price (1/128 bit)
@@ -73,6 +74,13 @@ struct EncLds {
             uint8_t fin_lit[kAPLimit + 3];
         };
         struct { uint16_t trie_next[300 * 26]; uint8_t trie_sym[304]; };     // word trie, only while the dictionary filter runs
+        struct {   // lazy levels: parse wavefront -> coder wavefront (see "token pipe"); the control words sit behind the
+                   // ring, i.e. beyond the 15.9 KiB the word trie uses, because the coder wavefront polls them while the
+                   // dictionary filter owns the front of this union
+            uint2 tok[kTokRing];
+            uint32_t pipe_cmd, pipe_ack, tok_head, tok_tail;
+            uint32_t hand[16];                // coder-side scalars handed between the two wavefronts
+        };
     };
     // the sub-block being parsed: stage[j] = wnd[stage_base + j - 16] (16 bytes of history, 48 of look-ahead)
     uint32_t stage[(kMinBlock + 64) / 4];
@@ -101,6 +109,7 @@ struct Sc {
     uint32_t stage_base, stage_end;   // window positions covered by L->stage: [stage_base - 16, stage_end)
     uint32_t cand_len_v, cand_dist_v; // mfcand_[1..]: candidate j lives in lane j of these two VGPRs
     uint32_t st_find, st_slide, st_bt, st_lit, st_match;
+    uint32_t pipe_ok, piped, tok_headl, tok_tail_seen, pipe_seq;   // token pipe (parse side): active?, local head, last tail seen, hand-over number
 #ifdef CSCMI_TIMERS
     unsigned long long tm[16];
 #endif
