@@ -46,10 +46,10 @@ __device__ static const uint32_t kDltIndex[5] = {1, 2, 3, 4, 8};   // csc_typede
 
 // ------------------------------------------------------------------------------------------
 // LDS image of one stream while k_encode_runs is resident (< 40 KiB: four streams per CU fit in 160 KiB)
-constexpr uint32_t kTokRing = 2048;
+constexpr uint32_t kTokRing = 2048, kTokRingSmall = 64;
 struct EncLds {
     uint32_t P[P_COUNT + 4];                  // small adaptive probability tables
-    uint32_t p2b[512];                        // probability -> price (1/128 bit)
+    uint16_t p2b[512];                        // probability -> price (1/128 bit; at most 12 * 128)
     uint32_t len_price[32], len_price_old[32];
     uint32_t rep[4];                          // rep_dist_[4] (live)
     uint32_t cd[32];                          // candidate distances of the position being searched: 0-3 rep, 4 HT2, 5 HT3, 6 BT head, 7.. bucket
@@ -74,14 +74,13 @@ struct EncLds {
             uint8_t fin_lit[kAPLimit + 3];
         };
         struct { uint16_t trie_next[300 * 26]; uint8_t trie_sym[304]; };     // word trie, only while the dictionary filter runs
-        struct {   // lazy levels: parse wavefront -> coder wavefront (see "token pipe"); the control words sit behind the
-                   // ring, i.e. beyond the 15.9 KiB the word trie uses, because the coder wavefront polls them while the
-                   // dictionary filter owns the front of this union
-            uint2 tok[kTokRing];
-            uint32_t pipe_cmd, pipe_ack, tok_head, tok_tail;
-            uint32_t hand[16];                // coder-side scalars handed between the two wavefronts
-        };
+        uint2 tok[kTokRing];                                                  // lazy levels: the token pipe's ring (the DP log is idle there)
     };
+    // token pipe (parse wavefront -> coder wavefront, see csc_kernels_lz.inc): control words, the coder-side scalars
+    // handed between the wavefronts, and the small ring the advanced parser uses (its DP log occupies the union above)
+    uint32_t pipe_cmd, pipe_ack, tok_head, tok_tail;
+    uint32_t hand[16];
+    uint2 tok_small[kTokRingSmall];
     // the sub-block being parsed: stage[j] = wnd[stage_base + j - 16] (16 bytes of history, 48 of look-ahead)
     uint32_t stage[(kMinBlock + 64) / 4];
 };
@@ -109,7 +108,8 @@ struct Sc {
     uint32_t stage_base, stage_end;   // window positions covered by L->stage: [stage_base - 16, stage_end)
     uint32_t cand_len_v, cand_dist_v; // mfcand_[1..]: candidate j lives in lane j of these two VGPRs
     uint32_t st_find, st_slide, st_bt, st_lit, st_match;
-    uint32_t pipe_ok, piped, tok_headl, tok_tail_seen, pipe_seq;   // token pipe (parse side): active?, local head, last tail seen, hand-over number
+    uint32_t pipe_ok, piped, tok_headl, tok_tail_seen, pipe_seq;
+    uint2 *tok_ring; uint32_t tok_mask;   // which ring this kernel's token pipe uses   // token pipe (parse side): active?, local head, last tail seen, hand-over number
 #ifdef CSCMI_TIMERS
     unsigned long long tm[16];
 #endif
