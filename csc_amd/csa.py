@@ -39,7 +39,8 @@ class CSAFrag(C.Structure):
 LIST_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(CSAFrag))
 
 SYMBOLS = ["CSA_OptionsInit", "CSA_Add", "CSA_Extract", "CSA_Test", "CSA_List", "CSA_ReadIndex",
-           "CSA_Adler32", "CSAMI_Adler32Device", "CSA_DecimalTime", "CSA_UnixTime"]
+           "CSA_Adler32", "CSAMI_Adler32Device", "CSA_DecimalTime", "CSA_UnixTime",
+           "CSAMI_AddShardEncode", "CSAMI_FreeBlob", "CSAMI_AddShardAssemble"]
 
 _lib = None
 
@@ -67,6 +68,14 @@ def lib():
         L.CSA_DecimalTime.restype = C.c_int64
         L.CSA_UnixTime.argtypes = [C.c_int64]
         L.CSA_UnixTime.restype = C.c_int64
+        L.CSAMI_AddShardEncode.argtypes = [names, C.c_int, C.POINTER(CSAOptions), C.c_int, C.c_int,
+                                           C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(CSAStats)]
+        L.CSAMI_AddShardEncode.restype = C.c_int
+        L.CSAMI_FreeBlob.argtypes = [C.c_void_p]
+        L.CSAMI_FreeBlob.restype = None
+        L.CSAMI_AddShardAssemble.argtypes = [C.c_char_p, names, C.c_int, C.POINTER(CSAOptions), C.POINTER(C.c_void_p),
+                                             C.POINTER(C.c_uint64), C.c_int, C.POINTER(CSAStats)]
+        L.CSAMI_AddShardAssemble.restype = C.c_int
         _lib = L
     return _lib
 
@@ -95,6 +104,30 @@ def add(arcname: str, filenames: Sequence[str], **opts):
     o, st = options(**opts), CSAStats()
     arr, n = _names(filenames)
     rc = lib().CSA_Add(arcname.encode(), arr, n, C.byref(o), C.byref(st))
+    return rc, st.as_dict()
+
+
+def add_shard_encode(filenames: Sequence[str], rank: int, world: int, **opts):
+    """this rank's tasks of `csarc a [opts] arc filenames...` encoded on its GPU -> (rc, blob bytes, stats dict)"""
+    o, st = options(**opts), CSAStats()
+    arr, n = _names(filenames)
+    ptr, ln = C.c_void_p(), C.c_uint64()
+    rc = lib().CSAMI_AddShardEncode(arr, n, C.byref(o), rank, world, C.byref(ptr), C.byref(ln), C.byref(st))
+    blob = b""
+    if rc == 0:
+        blob = C.string_at(ptr, ln.value)
+        lib().CSAMI_FreeBlob(ptr)
+    return rc, blob, st.as_dict()
+
+
+def add_shard_assemble(arcname: str, filenames: Sequence[str], blobs: Sequence[bytes], **opts):
+    """every rank's blob -> the archive `csarc a -t1` writes; -> (rc, stats dict)"""
+    o, st = options(**opts), CSAStats()
+    arr, n = _names(filenames)
+    keep = [C.create_string_buffer(b, len(b)) if len(b) else C.create_string_buffer(1) for b in blobs]
+    ptrs = (C.c_void_p * max(len(keep), 1))(*[C.cast(k, C.c_void_p) for k in keep])
+    lens = (C.c_uint64 * max(len(keep), 1))(*[len(b) for b in blobs])
+    rc = lib().CSAMI_AddShardAssemble(arcname.encode(), arr, n, C.byref(o), ptrs, lens, len(blobs), C.byref(st))
     return rc, st.as_dict()
 
 

@@ -22,6 +22,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -538,7 +539,9 @@ bool write_all(int fd, const uint8_t *p, uint64_t n, uint64_t off)
 
 // compress_mt, csarc.cpp:338-409, with ONE logical worker order but many streams in flight:
 // every task stream is what CompressionWorker::do_work (csa_worker.cpp:23-56) produces.
-int encode_tasks(std::vector<Task> &tasks, BlockIndex &abindex, int arc_fd, uint64_t &arc_end, const CSAOptions &o, CSAStats *st)
+// `emit(task, sink)` receives every finished task in task order (the order a single worker would have written them).
+typedef std::function<int(size_t, BlockSink &)> EmitFn;
+int encode_tasks(std::vector<Task> &tasks, const EmitFn &emit, const CSAOptions &o, CSAStats *st)
 {
     const size_t nt = tasks.size();
     if (!nt) return 0;
@@ -567,14 +570,11 @@ int encode_tasks(std::vector<Task> &tasks, BlockIndex &abindex, int arc_fd, uint
     std::vector<uint32_t> live;
 
     auto flush_written = [&]() -> int {
-        // append finished tasks in task-id order: the archive a single worker would have written
+        // hand finished tasks on in task-id order: the archive a single worker would have written
         while (next_write < nt && done[next_write]) {
             BlockSink *k = done[next_write];
-            std::vector<Extent> &ext = abindex[next_write];                 // csarc.cpp:393-394 (id == task index)
-            uint64_t pos = arc_end;
-            for (uint64_t sz : k->sizes) { ext.push_back(Extent{pos, sz}); pos += sz; }    // csa_io.h:559-573
-            if (!write_all(arc_fd, k->data.data(), k->data.size(), arc_end)) return WRITE_ERROR;
-            arc_end = pos;
+            int r = emit(next_write, *k);
+            if (r) return r;
             if (st) st->n_blocks += (uint32_t)k->sizes.size();
             delete k;
             done[next_write] = nullptr;
@@ -1073,59 +1073,215 @@ int64_t CSA_UnixTime(int64_t date)
     return days * 86400 + hour * 3600 + minute * 60 + second;
 }
 
+}   // extern "C"
+
+// ---- pieces of Add shared by the one-process path and the sharded (one process per GPU) path ----
+namespace {
+
+struct AddPlan {
+    CSAOptions o;
+    Index index;
+    std::vector<Task> tasks;
+};
+
+void plan_add(AddPlan &P, const char *const *filenames, int nfilenames, const CSAOptions *opt)
+{
+    if (opt) P.o = *opt; else CSA_OptionsInit(&P.o);
+    if (P.o.split_count <= 0) P.o.split_count = 1;                           // csarc.cpp:199-200
+    Selection sel = make_selection(filenames, nfilenames);
+    for (const std::string &f : sel.names) scan_path(P.index, sel, f, P.o.recurse != 0);
+    P.tasks = plan_tasks(P.index, P.o.split_count);
+    if (P.o.task_bytes) P.tasks = cap_tasks(P.tasks, P.o.task_bytes);
+}
+
+int open_archive(const char *arcname, const CSAOptions &o, int &fd)
+{
+    struct stat sb;
+    if (!o.overwrite && stat(arcname, &sb) == 0) {                           // csarc.cpp:474-483
+        fprintf(stderr, "Archive %s already exists, use -f to force overwrite\n", arcname);
+        return 1;
+    }
+    fd = open(arcname, O_RDWR | O_CREAT, 0666);                              // OutputFile::open: "rb+" else "wb+"
+    if (fd < 0) { perror(arcname); return WRITE_ERROR; }
+    if (ftruncate(fd, (off_t)kHeaderSize) != 0) { perror("ftruncate"); close(fd); fd = -1; return WRITE_ERROR; }   // csarc.cpp:559-564
+    return 0;
+}
+
+// one finished task -> archive blocks at the end of the archive (csa_io.h:559-573; id == task index, csarc.cpp:393-394)
+int append_task(int fd, uint64_t &arc_end, BlockIndex &abindex, size_t id, const uint64_t *sizes, size_t nsizes,
+                const uint8_t *data, uint64_t len)
+{
+    std::vector<Extent> &ext = abindex[id];
+    uint64_t pos = arc_end;
+    for (size_t i = 0; i < nsizes; i++) { ext.push_back(Extent{pos, sizes[i]}); pos += sizes[i]; }
+    if (pos - arc_end != len) return WRITE_ERROR;
+    if (!write_all(fd, data, len, arc_end)) return WRITE_ERROR;
+    arc_end = pos;
+    return 0;
+}
+
+// fragments, index stream, header: csarc.cpp:371-386, 219-288
+int finish_archive(int fd, uint64_t arc_end, AddPlan &P, const BlockIndex &abindex, const char *arcname, CSAStats *st)
+{
+    // fragments in task-id order, files in task order: what compress_mt records with one worker
+    for (size_t ti = 0; ti < P.tasks.size(); ti++)
+        for (const FilePiece &f : P.tasks[ti].files)
+            f.it->second.frags.push_back(CSAFrag{(uint32_t)ti, f.checksum, f.posblock, f.size, f.off});
+    std::vector<uint8_t> raw = pack_index(P.index, abindex, arcname), comp;
+    int rc = encode_index(raw, comp);
+    if (rc == 0 && !write_all(fd, comp.data(), comp.size(), arc_end)) rc = WRITE_ERROR;
+    if (rc) return rc;
+    uint8_t hdr[kHeaderSize];                                                // csarc.cpp:268-287
+    hdr[0] = 'C'; hdr[1] = 'S'; hdr[2] = 'A'; hdr[7] = '1';
+    store_le(hdr + 3, kMagicNum, 4);
+    store_le(hdr + 8, arc_end, 8);
+    store_le(hdr + 16, comp.size(), 4);
+    store_le(hdr + 20, raw.size(), 4);
+    if (!write_all(fd, hdr, kHeaderSize, 0)) return WRITE_ERROR;
+    if (st) {
+        st->index_raw_size = raw.size();
+        st->index_compressed_size = comp.size();
+        st->archive_bytes = arc_end + comp.size();
+        st->n_entries = (uint32_t)P.index.size();
+        st->n_tasks = (uint32_t)P.tasks.size();
+    }
+    return 0;
+}
+
+// shard blob: what one rank hands to the rank that writes the archive.  All fields little-endian.
+//   u32 'CSAS' | u32 tasks in the whole plan | u32 tasks in this blob
+//   per task: u32 id | u32 nfiles | nfiles x { u32 adler32, u64 posblock, u64 size } | u32 nblocks | nblocks x u64 size | u64 len | bytes
+constexpr uint32_t kShardMagic = 0x53415343u;
+
+}   // namespace
+
+extern "C" {
+
 int CSA_Add(const char *arcname, const char *const *filenames, int nfilenames, const CSAOptions *opt, CSAStats *st)
 {
     double t0 = now_s();
-    CSAOptions o;
-    if (opt) o = *opt; else CSA_OptionsInit(&o);
-    if (o.split_count <= 0) o.split_count = 1;                               // csarc.cpp:199-200
     if (st) memset(st, 0, sizeof(*st));
     if (CSCMI_DeviceCheck() != 0) return CSCMI_DEVICE_ERROR;
+    AddPlan P;
     {
+        CSAOptions o;
+        if (opt) o = *opt; else CSA_OptionsInit(&o);
         struct stat sb;
-        if (!o.overwrite && stat(arcname, &sb) == 0) {                       // csarc.cpp:474-483
+        if (!o.overwrite && stat(arcname, &sb) == 0) {                       // csarc.cpp:474-483, before the scan
             fprintf(stderr, "Archive %s already exists, use -f to force overwrite\n", arcname);
             return 1;
         }
     }
-    Selection sel = make_selection(filenames, nfilenames);
-    Index index;
-    for (const std::string &f : sel.names) scan_path(index, sel, f, o.recurse != 0);
-    std::vector<Task> tasks = plan_tasks(index, o.split_count);
-    if (o.task_bytes) tasks = cap_tasks(tasks, o.task_bytes);
-
-    int fd = open(arcname, O_RDWR | O_CREAT, 0666);                          // OutputFile::open: "rb+" else "wb+"
-    if (fd < 0) { perror(arcname); return WRITE_ERROR; }
-    if (ftruncate(fd, (off_t)kHeaderSize) != 0) { perror("ftruncate"); close(fd); return WRITE_ERROR; }   // csarc.cpp:559-564
+    plan_add(P, filenames, nfilenames, opt);
+    int fd = -1;
+    int rc = open_archive(arcname, P.o, fd);
+    if (rc) return rc;
     uint64_t arc_end = kHeaderSize;
-
     BlockIndex abindex;
-    int rc = encode_tasks(tasks, abindex, fd, arc_end, o, st);
-    if (rc == 0) {
-        // fragments in task-id order, files in task order: what compress_mt records with one worker (csarc.cpp:371-386)
-        for (size_t ti = 0; ti < tasks.size(); ti++)
-            for (const FilePiece &f : tasks[ti].files)
-                f.it->second.frags.push_back(CSAFrag{(uint32_t)ti, f.checksum, f.posblock, f.size, f.off});
-        std::vector<uint8_t> raw = pack_index(index, abindex, arcname), comp;
-        rc = encode_index(raw, comp);
-        if (rc == 0 && !write_all(fd, comp.data(), comp.size(), arc_end)) rc = WRITE_ERROR;
-        if (rc == 0) {
-            uint8_t hdr[kHeaderSize];                                        // csarc.cpp:268-287
-            hdr[0] = 'C'; hdr[1] = 'S'; hdr[2] = 'A'; hdr[7] = '1';
-            store_le(hdr + 3, kMagicNum, 4);
-            store_le(hdr + 8, arc_end, 8);
-            store_le(hdr + 16, comp.size(), 4);
-            store_le(hdr + 20, raw.size(), 4);
-            if (!write_all(fd, hdr, kHeaderSize, 0)) rc = WRITE_ERROR;
-            if (st) {
-                st->index_raw_size = raw.size();
-                st->index_compressed_size = comp.size();
-                st->archive_bytes = arc_end + comp.size();
-                st->n_entries = (uint32_t)index.size();
-                st->n_tasks = (uint32_t)tasks.size();
-            }
+    rc = encode_tasks(P.tasks, [&](size_t id, BlockSink &k) {
+        return append_task(fd, arc_end, abindex, id, k.sizes.data(), k.sizes.size(), k.data.data(), k.data.size());
+    }, P.o, st);
+    if (rc == 0) rc = finish_archive(fd, arc_end, P, abindex, arcname, st);
+    close(fd);
+    if (st) st->seconds_total = now_s() - t0;
+    return rc;
+}
+
+// ---- sharded Add: one process per GPU, tasks dealt round-robin in dispatch order ----
+int CSAMI_AddShardEncode(const char *const *filenames, int nfilenames, const CSAOptions *opt, int rank, int world,
+                         uint8_t **blob, uint64_t *blob_len, CSAStats *st)
+{
+    double t0 = now_s();
+    if (st) memset(st, 0, sizeof(*st));
+    if (!blob || !blob_len || world <= 0 || rank < 0 || rank >= world) return -1;
+    *blob = nullptr; *blob_len = 0;
+    if (CSCMI_DeviceCheck() != 0) return CSCMI_DEVICE_ERROR;
+    AddPlan P;
+    plan_add(P, filenames, nfilenames, opt);
+    std::vector<Task> mine;
+    std::vector<uint32_t> ids;
+    for (size_t i = 0; i < P.tasks.size(); i++)
+        if ((int)(i % (size_t)world) == rank) { mine.push_back(P.tasks[i]); ids.push_back((uint32_t)i); }   // csarc.cpp:355: dispatch order == id order
+    std::vector<uint8_t> out;
+    put_le(out, kShardMagic, 4);
+    put_le(out, P.tasks.size(), 4);
+    put_le(out, mine.size(), 4);
+    int rc = encode_tasks(mine, [&](size_t k, BlockSink &s) {
+        put_le(out, ids[k], 4);
+        put_le(out, mine[k].files.size(), 4);
+        for (const FilePiece &f : mine[k].files) { put_le(out, f.checksum, 4); put_le(out, f.posblock, 8); put_le(out, f.size, 8); }
+        put_le(out, s.sizes.size(), 4);
+        for (uint64_t z : s.sizes) put_le(out, z, 8);
+        put_le(out, s.data.size(), 8);
+        out.insert(out.end(), s.data.begin(), s.data.end());
+        return 0;
+    }, P.o, st);
+    if (rc) return rc;
+    uint8_t *b = (uint8_t *)malloc(out.size());
+    if (!b) return -1;
+    memcpy(b, out.data(), out.size());
+    *blob = b; *blob_len = out.size();
+    if (st) { st->n_tasks = (uint32_t)mine.size(); st->seconds_total = now_s() - t0; }
+    return 0;
+}
+
+void CSAMI_FreeBlob(uint8_t *blob) { free(blob); }
+
+int CSAMI_AddShardAssemble(const char *arcname, const char *const *filenames, int nfilenames, const CSAOptions *opt,
+                           const uint8_t *const *blobs, const uint64_t *blob_lens, int nblobs, CSAStats *st)
+{
+    double t0 = now_s();
+    if (st) memset(st, 0, sizeof(*st));
+    if (CSCMI_DeviceCheck() != 0) return CSCMI_DEVICE_ERROR;              // the index stream is encoded on the GPU
+    AddPlan P;
+    plan_add(P, filenames, nfilenames, opt);
+    struct Part { const uint8_t *files, *sizes, *data; uint32_t nfiles, nblocks; uint64_t len; };
+    std::vector<Part> parts(P.tasks.size(), Part{nullptr, nullptr, nullptr, 0, 0, 0});
+    for (int b = 0; b < nblobs; b++) {
+        const uint8_t *p = blobs[b], *end = p + blob_lens[b];
+        if (blob_lens[b] < 12 || load_le(p, 4) != kShardMagic || load_le(p + 4, 4) != P.tasks.size()) {
+            fprintf(stderr, "csa-mi355x: shard %d does not belong to this plan (input changed between ranks?)\n", b);
+            return -1;
+        }
+        uint32_t n = (uint32_t)load_le(p + 8, 4);
+        p += 12;
+        for (uint32_t k = 0; k < n; k++) {
+            if (end - p < 8) return -1;
+            uint32_t id = (uint32_t)load_le(p, 4), nf = (uint32_t)load_le(p + 4, 4);
+            p += 8;
+            if (id >= parts.size() || parts[id].data || nf != P.tasks[id].files.size() || (uint64_t)(end - p) < (uint64_t)nf * 20 + 4) return -1;
+            Part &q = parts[id];
+            q.files = p; q.nfiles = nf; p += (uint64_t)nf * 20;
+            q.nblocks = (uint32_t)load_le(p, 4); p += 4;
+            if ((uint64_t)(end - p) < (uint64_t)q.nblocks * 8 + 8) return -1;
+            q.sizes = p; p += (uint64_t)q.nblocks * 8;
+            q.len = load_le(p, 8); p += 8;
+            if ((uint64_t)(end - p) < q.len) return -1;
+            q.data = p; p += q.len;
         }
     }
+    for (size_t i = 0; i < parts.size(); i++)
+        if (!parts[i].data) { fprintf(stderr, "csa-mi355x: task %zu missing from the shards\n", i); return -1; }
+    int fd = -1;
+    int rc = open_archive(arcname, P.o, fd);
+    if (rc) return rc;
+    uint64_t arc_end = kHeaderSize;
+    BlockIndex abindex;
+    std::vector<uint64_t> sizes;
+    for (size_t i = 0; rc == 0 && i < parts.size(); i++) {
+        const Part &q = parts[i];
+        for (uint32_t f = 0; f < q.nfiles; f++) {
+            FilePiece &fp = P.tasks[i].files[f];
+            fp.checksum = (uint32_t)load_le(q.files + f * 20, 4);
+            fp.posblock = load_le(q.files + f * 20 + 4, 8);
+            fp.size = load_le(q.files + f * 20 + 12, 8);
+        }
+        sizes.resize(q.nblocks);
+        for (uint32_t k = 0; k < q.nblocks; k++) sizes[k] = load_le(q.sizes + k * 8, 8);
+        rc = append_task(fd, arc_end, abindex, i, sizes.data(), sizes.size(), q.data, q.len);
+        if (st) st->n_blocks += q.nblocks;
+    }
+    if (rc == 0) rc = finish_archive(fd, arc_end, P, abindex, arcname, st);
     close(fd);
     if (st) st->seconds_total = now_s() - t0;
     return rc;

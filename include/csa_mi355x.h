@@ -91,6 +91,20 @@ void CSA_OptionsInit(CSAOptions *o);
  * encoder or the file system fails (the reference ignores those). */
 int CSA_Add(const char *arcname, const char *const *filenames, int nfilenames, const CSAOptions *o, CSAStats *st);
 
+/* Sharded Add -- one process per GPU (the reference's counterpart is compress_mt, csarc.cpp:338-409,
+ * whose worker threads each take the next task of the size-sorted list and hand their archive blocks to
+ * one writer).  Every rank plans the same tasks from the same file names; rank r encodes tasks
+ * r, r + world, r + 2 world ... of the dispatch order (csarc.cpp:355) on ITS GPU and returns them as one
+ * opaque blob (malloc'ed; release with CSAMI_FreeBlob).  The caller moves the blobs to the writing rank
+ * (RCCL over xGMI in csc_amd/sharded.py -- the only exchange on this path) and calls CSAMI_AddShardAssemble
+ * there with all of them: the archive is byte for byte the one CSA_Add / `csarc a -t1` writes.
+ * Return values as CSA_Add; -1 for blobs that do not match the plan. */
+int CSAMI_AddShardEncode(const char *const *filenames, int nfilenames, const CSAOptions *o, int rank, int world,
+                         uint8_t **blob, uint64_t *blob_len, CSAStats *st);
+void CSAMI_FreeBlob(uint8_t *blob);
+int CSAMI_AddShardAssemble(const char *arcname, const char *const *filenames, int nfilenames, const CSAOptions *o,
+                           const uint8_t *const *blobs, const uint64_t *blob_lens, int nblobs, CSAStats *st);
+
 /* `csarc x`: 0 ok, 1 bad header (csarc.cpp:602-603), -1 decode error (csarc.cpp:464-468).
  * A failed adler32 is reported on stderr like the reference does and counted in st->verify_failures;
  * it does not change the return value (csa_io.h:331-332). */

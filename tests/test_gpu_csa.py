@@ -275,3 +275,65 @@ def test_task_bytes_gives_valid_archives_the_reference_reads(csa, tmp_path, monk
     assert rc == 0 and st["n_tasks"] == 127
     rc, st = csa.test("big.csa", mt_count=16)
     assert rc == 0 and st["verify_failures"] == 0 and st["raw_bytes"] == 3 << 20
+
+
+# ---------------------------------------------------------------------------------------------
+# sharded Add: tasks dealt over ranks, blobs gathered, archive assembled on rank 0
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case,world", [("mixed_tree", 2), ("many_files", 3), ("single_split3", 2), ("single_split_many", 8),
+                                        ("single_shadowed_by_empty", 2), ("named_files_m3", 4)])
+def test_sharded_add_equals_the_reference_archive(csa, case, world, tmp_path, monkeypatch):
+    """every rank's shard encoded one after the other on the one GPU of this box, then assembled: the archive must be
+    the reference's (the exchange itself is covered by the gloo tests)"""
+    csa_cases.make_tree(str(tmp_path), case)
+    monkeypatch.chdir(tmp_path)
+    spec = csa_cases.CSA_CASES[case]
+    opts = dict(spec["opts"], overwrite=True)
+    blobs, ntasks = [], 0
+    for r in range(world):
+        rc, blob, st = csa.add_shard_encode(spec["args"], r, world, **opts)
+        assert rc == 0
+        blobs.append(blob)
+        ntasks += st["n_tasks"]
+    rc, st = csa.add_shard_assemble(csa_cases.ARCNAME, spec["args"], blobs[::-1], **opts)    # blob order must not matter
+    assert rc == 0 and st["n_tasks"] == ntasks
+    arc = (tmp_path / csa_cases.ARCNAME).read_bytes()
+    assert cases.digest(arc) == GOLD[case]["archive_sha256"] and len(arc) == st["archive_bytes"]
+    # a shard that is missing, or that belongs to another plan, is refused
+    if ntasks > 1:
+        rc, _ = csa.add_shard_assemble("bad.csa", spec["args"], blobs[:-1], **opts)
+        assert rc == -1
+    rc, _ = csa.add_shard_assemble("bad.csa", spec["args"], blobs + [blobs[0]], **opts)
+    assert rc == -1 or ntasks == 0
+
+
+SHARD_WORKER = """
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import torch, torch.distributed as dist
+import csa_cases
+from csc_amd import sharded
+torch.cuda.set_device(0)                       # both ranks share the one GPU of this box, so the transport is gloo
+dist.init_process_group(backend="gloo")
+spec = csa_cases.CSA_CASES[%r]
+rc, st = sharded.add(csa_cases.ARCNAME, spec["args"], overwrite=True, **spec["opts"])
+assert rc == 0, rc
+print("RANK", dist.get_rank(), "tasks", st["n_tasks"], flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("case", ["many_files", "single_split_many"])
+def test_sharded_add_two_processes(csa, case, tmp_path):
+    """the whole multi-rank path, exchange included: two processes (gloo; one GPU between them) write the reference archive"""
+    csa_cases.make_tree(str(tmp_path), case)
+    script = tmp_path / "worker.py"
+    script.write_text(SHARD_WORKER % (ROOT, ROOT, case))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29577", str(script)], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert out.stdout.count("RANK") == 2
+    arc = (tmp_path / csa_cases.ARCNAME).read_bytes()
+    assert cases.digest(arc) == GOLD[case]["archive_sha256"]

@@ -70,3 +70,47 @@ def test_assignment_covers_every_task_once():
         assert max(len(r) for r in a) - min(len(r) for r in a) <= 1
     # largest first: the short last slice is dispatched last (csarc.cpp:355)
     assert tasks.dispatch_order(tl)[-1] == 7
+
+
+EXCHANGE = textwrap.dedent("""
+    import hashlib, os, sys
+    sys.path.insert(0, %r)
+    import torch.distributed as dist
+    from csc_amd import sharded
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo")
+    def blob_of(r):                      # ragged on purpose: rank 1 has nothing to send
+        n = 0 if r == 1 else 1000003 * (r + 1) + 17
+        return bytes((i * 131 + r * 7) & 0xFF for i in range(min(n, 4096))) * (n // 4096) + b"x" * (n %% 4096) if n else b""
+    got = sharded.gather_blobs(blob_of(rank), 0)
+    if rank == 0:
+        assert got is not None and len(got) == world
+        for r in range(world):
+            assert got[r] == blob_of(r), r
+        print("RESULT ok", [len(b) for b in got])
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+""") % (ROOT,)
+
+
+def _launch(src, world, port):
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(src)
+        path = f.name
+    try:
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                              "--master-addr", "127.0.0.1", "--master-port", str(port), path],
+                             capture_output=True, text=True, timeout=600)
+    finally:
+        os.unlink(path)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stdout
+
+
+def test_shard_blobs_reach_rank0_ragged():
+    """the one exchange of the sharded Add (csc_amd/sharded.py): variable-length blobs, an empty one among them"""
+    for world in (2, 3):
+        assert "RESULT ok" in _launch(EXCHANGE, world, 29560 + world)
