@@ -177,6 +177,8 @@ def main():
     ap.add_argument("--dict", default="64m")
     ap.add_argument("--cpu-sample-mib", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exchange", action="store_true",
+                    help="N > 1: skip the RCCL hand-over of the encoded streams to rank 0 (outside the timed region)")
     ap.add_argument("--multi-streams", default="127,954",
                     help="extra (N=1 only): the WHOLE 10^9-byte file as -p<S> task splits, all tasks concurrently on this GPU; '' = skip")
     args = ap.parse_args()
@@ -257,6 +259,27 @@ def main():
         dist.all_reduce(tot_bytes, op=dist.ReduceOp.SUM)
     tmax, tot_bytes = float(tmax.item()), float(tot_bytes.item())
 
+    # N > 1, outside the timed region: the one exchange of the sharded archiver (csc_amd/sharded.py) --
+    # every rank's encoded stream so far goes to rank 0 as a device tensor over RCCL, rank 0 checks the digests
+    exchange = None
+    if world > 1 and not args.no_exchange:
+        try:
+            import hashlib
+            from csc_amd import sharded
+            meta = [None] * world
+            dist.all_gather_object(meta, (len(gpu_stream), hashlib.sha256(gpu_stream).hexdigest()))
+            barrier()
+            te = time.perf_counter()
+            got = sharded.gather_blobs(gpu_stream, 0)
+            barrier()
+            te = time.perf_counter() - te
+            if rank == 0:
+                ok = all(len(got[r]) == meta[r][0] and hashlib.sha256(got[r]).hexdigest() == meta[r][1] for r in range(world))
+                exchange = {"what": "encoded task streams of all ranks -> rank 0 (all_gather of lengths + grouped RCCL send/recv of device tensors)",
+                            "ok": bool(ok), "bytes": int(sum(m[0] for m in meta)), "seconds": round(te, 4)}
+        except Exception as e:      # never lose the bench line to the hand-over
+            exchange = {"ok": False, "error": repr(e)[:300]}
+
     if rank == 0:
         launches = s1.encode_launches - s0.encode_launches
         kern_ms = s1.encode_kernel_ms - s0.encode_kernel_ms
@@ -267,6 +290,17 @@ def main():
         avg_ms = kern_ms / max(1, launches)
         bytes_per_launch = in_b / max(1, launches)
         achieved = balg * bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc runs of this very
+        # command; counters cannot be read from inside the process).  The committed measurement is scaled by input bytes.
+        traffic, traffic_note = None, "no PMC measurement committed for this configuration"
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            ent = pmc.get(f"m{level}_d{args.dict}_single_stream")
+            if ent and world == 1:
+                traffic = round((ent["fetch_bytes_per_input_byte"] + ent["write_bytes_per_input_byte"]) * bytes_per_launch)
+                traffic_note = ent["source"]
+        except (OSError, ValueError, KeyError):
+            pass
         line = {
             "metric": "encode MB/s (10^6 input bytes / wall-clock) on the enwik9 stand-in, -m3 -d64m; stream bit-exact vs reference",
             "value": round(tot_bytes / 1e6 / tmax, 4),
@@ -284,7 +318,7 @@ def main():
                        "hash_width": int(props.hash_width), "good_len": int(props.good_len), "lz_mode": int(props.lz_mode)},
             "ratio": round(ratio, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "k_encode_runs", "launches": int(launches),
                          "avg_launch_ms": round(avg_ms, 3), "alg_bytes_per_input_byte": round(balg, 3),
                          "input_bytes_per_launch": round(bytes_per_launch, 1),
@@ -302,6 +336,8 @@ def main():
             line["bit_exact_vs_cpu_baseline"] = bool(cpu_stream[:len(gpu_stream)] == gpu_stream)
         else:
             line["cpu_baseline"] = None
+        if exchange is not None:
+            line["exchange"] = exchange
     L.CSCEnc_Encode_Flush(h)
     L.CSCEnc_Destroy(h)
     if rank == 0:

@@ -84,6 +84,32 @@ def test_config2_geometry_roundtrip_and_parity(prod, orc, zalloc):
     assert (rc, s) == orc.encode(data, props=orc.props_init(64 << 20, 3), alloc=zalloc)
 
 
+def test_config3_geometry_roundtrip_and_parity(prod, orc, zalloc):
+    """BASELINE configs[2] geometry (silesia-like 211 957 760 B at -m5 -d256m: binary tree with a 24-bit head and
+    78 157 824 nodes, no HT6) on a bounded prefix of the silesia stand-in"""
+    data = cases.build([["silesia", 6, 0, 2 << 20], ["silesia", 6, 90 << 20, 1 << 20]])
+    p = prod.props_init(min(256 << 20, 211957760), 5)
+    assert (p.hash_width, p.bt_hash_bits, p.bt_size, p.bt_cyc, p.good_len, p.lz_mode) == (0, 24, 78157824, 32, 48, 3)
+    rc, s = prod.encode(data, props=p)
+    assert rc == 0 and prod.decode(s) == (0, data)
+    assert (rc, s) == orc.encode(data, props=orc.props_init(min(256 << 20, 211957760), 5), alloc=zalloc)
+
+
+def test_config5_geometry_roundtrip_and_parity(prod, orc, zalloc):
+    """BASELINE configs[4] geometry (10 GB EXE|text|delta mix, -m2 -d1024m -p8: 1 GiB window, 23-bit x 8 HT6, lazy
+    parser): two stretches of the mix straddling its 64 MiB segment seams, so that the analyzer switches between
+    the e8e9, dictionary and delta paths inside one stream"""
+    from csc_amd import corpus
+    seg = 64 << 20
+    data = (corpus.fill("mix5", corpus.SEED_EXE, seg - (1 << 20), 2 << 20).tobytes()
+            + corpus.fill("mix5", corpus.SEED_EXE, 2 * seg - (1 << 20), 2 << 20).tobytes())
+    p = prod.props_init(1 << 30, 2)
+    assert (p.dict_size, p.hash_bits, p.hash_width, p.good_len, p.lz_mode) == (1 << 30, 23, 8, 24, 2)
+    rc, s = prod.encode(data, props=p)
+    assert rc == 0 and prod.decode(s) == (0, data)
+    assert (rc, s) == orc.encode(data, props=orc.props_init(1 << 30, 2), alloc=zalloc)
+
+
 def test_device_resident_chunks_equal_host_path(prod):
     import torch
     from csc_amd.capi import BytesWriter
