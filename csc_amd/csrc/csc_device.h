@@ -42,7 +42,7 @@ enum : uint32_t {
     P_COUNT = P_RLE_FLAG + 1
 };
 
-enum : uint32_t { ERR_NONE = 0, ERR_ARENA_FULL = 1, ERR_BAD_TYPE = 2 };
+enum : uint32_t { ERR_NONE = 0, ERR_ARENA_FULL = 1, ERR_BAD_TYPE = 2, ERR_PAIR_STALL = 3 };
 
 // one finished coder block in the output arena: 16-byte header, payload padded to 16
 struct ArenaRec {

@@ -287,7 +287,7 @@ int drain_arena(EncInstance *e, int ev_used)
     uint32_t used = e->h_small[0], err = e->h_small[1];
     if (err != ERR_NONE) {
         fprintf(stderr, "csc-mi355x: device encoder error %u (%s)\n", err,
-                err == ERR_ARENA_FULL ? "output arena exhausted" : "bad block type");
+                err == ERR_ARENA_FULL ? "output arena exhausted" : err == ERR_PAIR_STALL ? "parse wavefronts lost step" : "bad block type");
         return CSCMI_DEVICE_ERROR;
     }
     if (used) {
