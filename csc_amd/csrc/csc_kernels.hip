@@ -47,6 +47,7 @@ __device__ static const uint32_t kDltIndex[5] = {1, 2, 3, 4, 8};   // csc_typede
 // ------------------------------------------------------------------------------------------
 // LDS image of one stream while k_encode_runs is resident (< 40 KiB: four streams per CU fit in 160 KiB)
 constexpr uint32_t kTokRing = 2048;
+constexpr uint32_t kDpWaves = 4;          // parse wavefronts per stream the advanced parser can use (csc_kernels_dp2.inc)
 // Advanced parser on two parse wavefronts (csc_kernels_dp2.inc): what the wavefront that visited DP node k leaves for the
 // visitor of node k + 1, and the control words of a DP window.
 struct DpEdge {
@@ -59,21 +60,23 @@ struct DpShared {
     uint32_t cmd, idle;        // master -> helper: window number (kPipeQuit at kernel end); helper -> master: window left
     uint32_t dec;              // ((k + 1) << 2) | way out: decision of node k (0 = the window goes on)
     uint32_t price_done, relax_done;   // k + 1 once node k's length pricing / relaxation is complete (both are ordered across nodes)
+    uint32_t ins_done, erep_done;      // k + 1 once position k's table insert has completed / node k's rep distances + state are in er[]
     uint32_t lp_int;           // GetMatchLenPrice's refresh countdown while a window is open
-    uint32_t abort, pad;
+    uint32_t abort, gate;      // gate: see dp_undo
     uint32_t wpos0, pos0, aplimit, limit0, stage_base, stage_end;   // the open window
     uint32_t bstat[2];
     DpEdge e[2];               // mailbox of node k at [k & 1]
+    uint32_t er[2][8];         // rep distances [0..3] and coder state [4] of node k at [k & 1], published as soon as its label is final
 };
 struct EncLds {
     uint32_t P[P_COUNT + 4];                  // small adaptive probability tables
-    uint32_t p2b[512];                        // probability -> price (1/128 bit)
+    uint16_t p2b[512];                        // probability -> price (1/128 bit; at most 12 * 128)
     uint32_t len_price[32], len_price_old[32];
     uint32_t rep[4];                          // rep_dist_[4] (live)
-    uint32_t cd2[2][32];                      // candidate distances of the position being searched: 0-3 rep, 4 HT2, 5 HT3, 6 BT head, 7.. bucket
+    uint32_t cd2[kDpWaves][32];                      // candidate distances of the position being searched: 0-3 rep, 4 HT2, 5 HT3, 6 BT head, 7.. bucket
                                               // ([wavefront]: the advanced parser of the hash-table configurations runs two parse wavefronts)
     uint32_t cmp_pos[16], cmp_lim[16], cmp_res[16];
-    uint32_t rp42[2][4];                      // the four rep-index prices of the position being priced ([wavefront])
+    uint32_t rp42[kDpWaves][4];                     // the four rep-index prices of the position being priced ([wavefront])
     // The parser's DP nodes (APUnit, csc_lz.h:33-41) as a 256-slot ring + a per-node log.  A node is
     // relabelled only from nodes before it and only up to good_len - 1 <= 254 positions ahead, so
     // the live frontier (price, label, coder state, rep distances) fits a ring indexed by node & 255;
@@ -128,7 +131,7 @@ struct Sc {
     uint32_t lane;
     uint32_t stage_base, stage_end;   // window positions covered by L->stage: [stage_base - 16, stage_end)
     uint32_t cand_len_v, cand_dist_v; // mfcand_[1..]: candidate j lives in lane j of these two VGPRs
-    uint32_t wv, dp_seq;              // which parse wavefront this is (0 master, 1 helper: scratch row in cd2 / rp42); DP windows opened so far
+    uint32_t wv, dp_seq, dp_idle;              // which parse wavefront this is (0 master, 1 helper: scratch row in cd2 / rp42); DP windows opened so far
     uint32_t st_find, st_slide, st_bt, st_lit, st_match;
     uint32_t pipe_ok, piped, tok_headl, tok_tail_seen, pipe_seq, pair_ok;   // token pipe (parse side): active?, local head, last tail seen, hand-over number
 #ifdef CSCMI_TIMERS

@@ -9,7 +9,8 @@ from csc_amd import corpus
 from csc_amd.capi import CscLib, BytesWriter
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 mib = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-lib = CscLib(os.path.join(ROOT, "csc_amd", "libcsc_mi355x_timers.so"))
+lib = CscLib(sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "csc_amd", "libcsc_mi355x_timers.so"))
+PAIR = len(sys.argv) > 3
 class St(C.Structure):
     _fields_ = [("chunks", C.c_uint64), ("input_bytes", C.c_uint64), ("output_bytes", C.c_uint64), ("encode_launches", C.c_uint64),
                 ("encode_kernel_ms", C.c_double), ("analyze_kernel_ms", C.c_double), ("find", C.c_uint64), ("slide", C.c_uint64),
@@ -29,6 +30,9 @@ lib.lib.CSCMI_DebugTimers.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 tm = (C.c_uint64 * 16)(); lib.lib.CSCMI_DebugTimers(h, tm)
 names = ["fm:hash+gather", "fm:slots+extend", "fm:replay+insert", "pricing", "dp:statefix", "dp:litprice+relax", "dp:exit(backward+encode+slide)",
          "slide_pos", "dict filter", "window memcpy", "lazy: symbol coding", "lazy: FindMatch pick", "-", "-", "-", "-"]
+if PAIR:
+    names = ["M pre:tables", "M pre:wait labels", "M pre:reps+lit", "M wait decision", "M crit", "M post:pricing", "M post:relax", "M way out",
+             "H pre:tables", "H pre:wait labels", "H pre:reps+lit", "H wait decision", "H crit", "H post:pricing", "H post:relax", "-"]
 tot = sum(tm)
 print(f"level {level}: {len(data)/1e6/dt:.3f} MB/s, kernel {st.encode_kernel_ms:.0f} ms, find_match {st.find}, slide {st.slide}, lit {st.lit}, match {st.match}")
 for n, v in zip(names, tm):
