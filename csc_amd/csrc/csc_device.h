@@ -74,6 +74,7 @@ struct KernelStats {          // counters for bench / DESIGN.md (SURVEY section 
     unsigned long long literals;
     unsigned long long matches;
     unsigned long long tm[16];   // cycle accumulators, filled only by -DCSCMI_TIMERS development builds
+    unsigned long long trace[64][12];   // event times of one DP window's nodes (-DCSCMI_TIMERS builds, tools/gpu_trace.py)
 };
 
 struct EncState {

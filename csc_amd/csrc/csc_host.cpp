@@ -742,4 +742,14 @@ void CSCMI_DebugTimers(CSCEncHandle p, uint64_t *out16)
     for (int i = 0; i < 16; i++) out16[i] = ks.tm[i];
 }
 
+void CSCMI_DebugTrace(CSCEncHandle p, uint64_t *out768)
+{
+    EncInstance *e = (EncInstance *)p;
+    static KernelStats ks;
+    memset(&ks, 0, sizeof(ks));
+    (void)hipSetDevice(e->device);
+    (void)hipMemcpy(&ks, &e->d_state->stats, sizeof(ks), hipMemcpyDeviceToHost);
+    memcpy(out768, ks.trace, sizeof(ks.trace));
+}
+
 }  // extern "C"

@@ -131,7 +131,7 @@ struct Sc {
     uint32_t lane;
     uint32_t stage_base, stage_end;   // window positions covered by L->stage: [stage_base - 16, stage_end)
     uint32_t cand_len_v, cand_dist_v; // mfcand_[1..]: candidate j lives in lane j of these two VGPRs
-    uint32_t wv, dp_seq, dp_idle;              // which parse wavefront this is (0 master, 1 helper: scratch row in cd2 / rp42); DP windows opened so far
+    uint32_t wv, dp_seq, dp_idle, dp_seq_seen;              // which parse wavefront this is (0 master, 1 helper: scratch row in cd2 / rp42); DP windows opened so far
     uint32_t st_find, st_slide, st_bt, st_lit, st_match;
     uint32_t pipe_ok, piped, tok_headl, tok_tail_seen, pipe_seq, pair_ok;   // token pipe (parse side): active?, local head, last tail seen, hand-over number
 #ifdef CSCMI_TIMERS
