@@ -66,7 +66,7 @@ struct DpShared {
     uint32_t wpos0, pos0, aplimit, limit0, stage_base, stage_end;   // the open window
     uint32_t bstat[2];
     DpEdge e[2];               // mailbox of node k at [k & 1]
-    uint32_t er[2][8];         // rep distances [0..3] and coder state [4] of node k at [k & 1], published as soon as its label is final
+    uint32_t er[4][8];         // rep distances [0..3] and coder state [4] of node k at [k & 3], published as soon as its label is final
 };
 struct EncLds {
     uint32_t P[P_COUNT + 4];                  // small adaptive probability tables
