@@ -66,6 +66,7 @@ struct DpShared {
     uint32_t wpos0, pos0, aplimit, limit0, stage_base, stage_end;   // the open window
     uint32_t bstat[2];
     DpEdge e[2];               // mailbox of node k at [k & 1]
+    uint16_t st_lit[64], st_p1[64];   // per coder state: price of the literal flag / of the rep0len1 flags, while a window is open
     uint32_t er[4][8];         // rep distances [0..3] and coder state [4] of node k at [k & 3], published as soon as its label is final
 };
 struct EncLds {
