@@ -322,7 +322,7 @@ def main():
                          "kernel": "k_encode_runs", "launches": int(launches),
                          "avg_launch_ms": round(avg_ms, 3), "alg_bytes_per_input_byte": round(balg, 3),
                          "input_bytes_per_launch": round(bytes_per_launch, 1),
-                         "note": "one wavefront per stream: the libcsc chain is latency-bound, not bandwidth-bound"},
+                         "note": "one stream = one workgroup of up to four parse wavefronts: the libcsc chain is latency/issue-bound, not bandwidth-bound"},
             "counters": {"find_match_calls": int(s1.find_match_calls - s0.find_match_calls),
                          "slide_positions": int(s1.slide_positions - s0.slide_positions),
                          "literals": int(s1.literals - s0.literals), "matches": int(s1.matches - s0.matches),
