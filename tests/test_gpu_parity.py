@@ -110,6 +110,60 @@ def test_config5_geometry_roundtrip_and_parity(prod, orc, zalloc):
     assert (rc, s) == orc.encode(data, props=orc.props_init(1 << 30, 2), alloc=zalloc)
 
 
+def test_advanced_parser_wavefront_counts(prod, orc, zalloc):
+    """The advanced parser of the hash-table levels runs 4, 2 or 1 parse wavefronts per stream depending on how many
+    streams a launch carries (<= 256, <= 512, more).  Same bytes in every case: batches of 3, 300 and 520 small task
+    streams (mixed text / exe, ragged sizes, some empty) against the oracle, at levels 3 and 4."""
+    import torch
+    from csc_amd import corpus
+    from csc_amd.capi import BytesWriter
+    L = prod.lib
+    L.CSCMI_EncodeDeviceChunkBatch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    want = {}
+    for count, level in ((3, 3), (300, 3), (520, 4), (300, 4)):
+        datas = []
+        for i in range(count):
+            n = 0 if i % 97 == 96 else 9000 + (i * 7919) % 30000
+            kind = "exe" if i % 5 == 4 else "text"
+            datas.append(corpus.fill(kind, 4000 + i % 11, (i % 13) * 50000, n).tobytes())
+        hs, ws, devs = [], [], []
+        for d in datas:
+            p = prod.props_init(max(len(d), 1), level)
+            w = BytesWriter()
+            h = L.CSCEnc_Create(C.byref(p), C.cast(w.ptr(), C.c_void_p), None)
+            assert h
+            w.out += prod.write_properties(p)
+            hs.append(h); ws.append(w)
+            devs.append(torch.frombuffer(bytearray(d) if d else bytearray(1), dtype=torch.uint8).cuda())
+        torch.cuda.synchronize()
+        live = [i for i, d in enumerate(datas) if d]
+        H = (C.c_void_p * len(live))(*[hs[i] for i in live])
+        P = (C.c_void_p * len(live))(*[devs[i].data_ptr() for i in live])
+        Z = (C.c_size_t * len(live))(*[len(datas[i]) for i in live])
+        assert L.CSCMI_EncodeDeviceChunkBatch(len(live), H, P, Z) == 0
+        for i, h in enumerate(hs):
+            assert L.CSCEnc_Encode_Flush(h) == 0
+            L.CSCEnc_Destroy(h)
+        for i, d in enumerate(datas):
+            key = (level, d)
+            if key not in want:
+                want[key] = orc.encode(d, props=orc.props_init(max(len(d), 1), level), alloc=zalloc)[1]
+            assert bytes(ws[i].out) == want[key], (count, level, i)
+
+
+def test_advanced_parser_one_wavefront_fallbacks(prod, orc, zalloc):
+    """Custom props for which the multi-wavefront DP steps aside inside the same kernel: good_len beyond the 64 lengths
+    the per-lane price table holds (the one-wavefront form runs while the helper wavefronts idle), and a 9-wide bucket."""
+    data = cases.build([["text", 61, 0, 250000], ["exe", 62, 0, 120000], ["text", 61, 40000, 90000]])
+    for tweak in ({"good_len": 100}, {"good_len": 65}, {"good_len": 64}, {"hash_width": 9, "hash_bits": 15}, {"hash_width": 1}):
+        p = prod.props_init(1 << 20, 3)
+        q = orc.props_init(1 << 20, 3)
+        for k, v in tweak.items():
+            setattr(p, k, v)
+            setattr(q, k, v)
+        assert prod.encode(data, props=p) == orc.encode(data, props=q, alloc=zalloc), tweak
+
+
 def test_device_resident_chunks_equal_host_path(prod):
     import torch
     from csc_amd.capi import BytesWriter
