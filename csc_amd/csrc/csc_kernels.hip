@@ -4,19 +4,24 @@
 //  * k_analyze / k_dup_check are wide kernels: one workgroup per 8 KiB block
 //     -- these are the embarrassingly parallel
 //    stages.
-//  * k_encode_runs is ONE wavefront per stream.  A libcsc stream is a strictly
+//  * k_encode_runs is ONE WORKGROUP per stream.  A libcsc stream is a strictly
 //    serial dependency chain (adaptive probabilities -> prices -> parse ->
-//    match-finder state), so the wavefront executes that protocol with
+//    match-finder state), so a wavefront executes that protocol with
 //    wave-uniform control flow while its 64 lanes cooperate on the byte work
 //    inside each step: all match candidates of a position are extended at once
 //    (4 lanes x 8 bytes per candidate, __ballot + ctz), hash-bucket gathers and
 //    shift-inserts are one vector memory op, price tables and the parser's DP
 //    relaxation are filled one length per lane, and the order-1 literal coder
 //    fetches/updates its 8 probabilities in 8 lanes before the (serial)
-//    range-coder arithmetic.  Small adaptive tables, the DP nodes and the word
-//    trie live in LDS; window, hash tables / binary tree and p_lit live in HBM.
-//    Independent streams (the archiver's -p / per-extension tasks) run as
-//    independent wavefronts on other CUs / GPUs.
+//    range-coder arithmetic.  Where the protocol leaves room, more wavefronts
+//    of the workgroup take part: the lazy levels run a parse wavefront feeding
+//    a coder wavefront through an LDS token ring (csc_kernels_lz.inc), the
+//    advanced parser of the hash-table levels runs up to four parse wavefronts
+//    that take the DP nodes of a window in turn (csc_kernels_dp2.inc).  Small
+//    adaptive tables, the DP nodes and the word trie live in LDS; window, hash
+//    tables / binary tree and p_lit live in HBM.  Independent streams (the
+//    archiver's -p / per-extension tasks) run as independent workgroups on
+//    other CUs / GPUs.
 //
 // No MFMA here: there is no dense contraction anywhere on this path.
 #include <hip/hip_runtime.h>
