@@ -26,6 +26,7 @@
 // No MFMA here: there is no dense contraction anywhere on this path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "csc_device.h"
 #include "csc_tables.h"
