@@ -286,8 +286,9 @@ int drain_arena(EncInstance *e, int ev_used)
     }
     uint32_t used = e->h_small[0], err = e->h_small[1];
     if (err != ERR_NONE) {
-        fprintf(stderr, "csc-mi355x: device encoder error %u (%s)\n", err,
-                err == ERR_ARENA_FULL ? "output arena exhausted" : err == ERR_PAIR_STALL ? "parse wavefronts lost step" : "bad block type");
+        // anything else is the watchdog of the multi-wavefront parser (csc_kernels_dp2.inc): the value says which wait gave up
+        fprintf(stderr, "csc-mi355x: device encoder error 0x%x (%s)\n", err,
+                err == ERR_ARENA_FULL ? "output arena exhausted" : err == ERR_BAD_TYPE ? "bad block type" : "parse wavefronts lost step");
         return CSCMI_DEVICE_ERROR;
     }
     if (used) {

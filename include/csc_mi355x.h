@@ -31,7 +31,8 @@ extern "C" {
 #define WRITE_ERROR (-97)                  /* csc_common.h:14 */
 #define READ_ERROR (-98)                   /* csc_common.h:15 */
 #define CSC_WRITE_ABORT ((size_t)-1)       /* csc_common.h:17 */
-/* Not in the reference: the GPU side failed (no device, HIP error, output arena exhausted).
+/* Not in the reference: the GPU side failed (no device, HIP error, output arena exhausted, or the watchdog of the
+ * multi-wavefront parser tripped -- a bug, reported instead of hanging the GPU).
  * Returned by CSCEnc_Encode / CSCEnc_Encode_Flush only; details go to stderr. */
 #define CSCMI_DEVICE_ERROR (-95)
 
