@@ -111,9 +111,10 @@ def test_config5_geometry_roundtrip_and_parity(prod, orc, zalloc):
 
 
 def test_advanced_parser_wavefront_counts(prod, orc, zalloc):
-    """The advanced parser of the hash-table levels runs 4, 2 or 1 parse wavefronts per stream depending on how many
-    streams a launch carries (<= 256, <= 512, more).  Same bytes in every case: batches of 3, 300 and 520 small task
-    streams (mixed text / exe, ragged sizes, some empty) against the oracle, at levels 3 and 4."""
+    """The advanced parser of the hash-table levels runs 4 parse wavefronts per stream while a launch carries <= 512
+    streams (one workgroup a CU up to 256 streams, the 256-VGPR instance with two workgroups a CU beyond) and 1 above that.
+    Same bytes in every case: batches of 3, 300 and 520 small task streams (mixed text / exe, ragged sizes, some empty)
+    against the oracle, at levels 3 and 4."""
     import torch
     from csc_amd import corpus
     from csc_amd.capi import BytesWriter
