@@ -34,7 +34,7 @@ if PAIR:
     names = ["M pre:tables", "M pre:wait labels", "M pre:reps+lit", "M wait decision", "M crit", "M post:pricing", "M post:relax", "M way out",
              "H pre:tables", "H pre:wait labels", "H pre:reps+lit", "H wait decision", "H crit", "H post:pricing", "H post:relax", "-"]
 tot = sum(tm)
-print(f"level {level}: {len(data)/1e6/dt:.3f} MB/s, kernel {st.encode_kernel_ms:.0f} ms, find_match {st.find}, slide {st.slide}, lit {st.lit}, match {st.match}")
+print(f"level {level}: {len(data)/1e6/dt:.3f} MB/s, kernel {st.encode_kernel_ms:.0f} ms, find_match {st.find}, slide {st.slide}, lit {st.lit}, match {st.match}, bt {st.bt} = redo_y {st.bt >> 16} redo_x {st.bt & 0xFFFF}")
 for n, v in zip(names, tm):
     if v: print(f"  {n:34s} {v/1e6:10.1f} Mcyc  {100*v/tot:5.1f}%   {v/max(1,st.find):8.0f} cyc/find_match")
 print(f"  total timed {tot/1e6:.1f} Mcyc -> {tot/max(1e-9,st.encode_kernel_ms*1e-3)/1e9:.2f} GHz-equivalent of kernel time")
