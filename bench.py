@@ -161,10 +161,19 @@ def multi_stream_job(lib, stream_counts, level, dict_size):
         # and back: every task stream through the HIP decoder, 256 streams per launch (one per CU), checked byte for byte
         dec = decode_all(lib, [bytes(w.out) for w in ws], whole, slices)
         balg = ALG_BYTES.get(level, 42.0) + out / total
+        # what the REFERENCE produces for this split (tests/golden/multi_stream_digests.json, recorded by
+        # tools/make_golden_multi.py from oracle/_ref): the whole 10^9 bytes, bit for bit
+        bit_exact = None
+        try:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "multi_stream_digests.json")))
+            if gold["level"] == level and gold["dict"] == dict_size and str(S) in gold["splits"]:
+                bit_exact = bool(gold["splits"][str(S)]["sha256_of_stream_sha256s"] == digest)
+        except (OSError, ValueError, KeyError):
+            pass
         results.append({"what": f"whole enwik9 stand-in (10^9 B) as csarc -m{level} -d64m -p{S}: {S} independent task streams, one workgroup each, 1 GPU",
                         "value": round(total / 1e6 / dt, 3), "unit": "MB/s", "seconds": round(dt, 2), "ratio": round(out / total, 4),
                         "streams": S, "batch_launches": k, "hbm_roofline_frac": round(balg * total / dt / 1e9 / HBM_PEAK_GBS, 8),
-                        "sha256_of_stream_sha256s": digest, "decode": dec})
+                        "sha256_of_stream_sha256s": digest, "bit_exact_vs_reference_digest": bit_exact, "decode": dec})
     return {"multi_stream": results}
 
 

@@ -109,3 +109,17 @@ def test_filters(orc):
     assert STAGES["filters"]["text/1/16383"]["dict_ok"] == 0
     assert STAGES["filters"]["text/1/16384"]["dict_ok"] == 1
     assert STAGES["filters"]["random/4/70000"]["dict_ok"] == 0
+
+
+def test_multi_stream_digest_fixture_is_wellformed():
+    """tests/golden/multi_stream_digests.json (reference digests of the whole 10^9-byte file as -p127 / -p954 task streams,
+    tools/make_golden_multi.py): bench.py compares its GPU run with them; here only the shape, and that the split sizes
+    are the archiver's (csarc.cpp:532-543)"""
+    import json
+    from csc_amd import corpus
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "multi_stream_digests.json")))
+    assert g["level"] == 3 and g["dict"] == 64 << 20 and g["total"] == 10 ** 9
+    for want in (127, 954):
+        assert len(corpus.task_slices(g["total"], want)) == want
+        e = g["splits"][str(want)]
+        assert len(e["sha256_of_stream_sha256s"]) == 64 and 0.2 < e["stream_bytes"] / g["total"] < 0.3
