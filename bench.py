@@ -204,10 +204,17 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # CSC_BENCH_BACKEND=gloo (tests only): the N > 1 code path with several ranks sharing one GPU; the driver's runs use RCCL
+    backend = os.environ.get("CSC_BENCH_BACKEND", "nccl")
+    local_dev = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group(backend=backend)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     level, dict_size = args.level, parse_size(args.dict)
     lib = csc_amd.load()
@@ -261,8 +268,8 @@ def main():
     L.CSCMI_GetStats(h, C.byref(s1))
     gpu_stream = bytes(writer.out)       # header + every finished chunk (no EOF yet): a prefix of the full stream
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    tot_bytes = torch.tensor([float(timed_bytes)], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    tot_bytes = torch.tensor([float(timed_bytes)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot_bytes, op=dist.ReduceOp.SUM)

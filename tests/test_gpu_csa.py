@@ -337,3 +337,19 @@ def test_sharded_add_two_processes(csa, case, tmp_path):
     assert out.stdout.count("RANK") == 2
     arc = (tmp_path / csa_cases.ARCNAME).read_bytes()
     assert cases.digest(arc) == GOLD[case]["archive_sha256"]
+
+
+def test_bench_multi_rank_path_two_processes(tmp_path):
+    """bench.py's N > 1 branch (task r on rank r, barrier + max-over-ranks timing, hand-over of the streams to rank 0) with
+    two ranks sharing the one GPU of this box over gloo (CSC_BENCH_BACKEND, tests only; the driver's runs use RCCL)"""
+    env = dict(os.environ, CSC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29583", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, out.stdout[-2000:]
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["exchange"]["ok"] is True and d["exchange"]["bytes"] > 0
+    assert 0 < d["value"] < 100 and d["roofline"]["launches"] == 1
