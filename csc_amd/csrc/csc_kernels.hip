@@ -54,6 +54,7 @@ __device__ static const uint32_t kDltIndex[5] = {1, 2, 3, 4, 8};   // csc_typede
 // LDS image of one stream while k_encode_runs is resident (< 40 KiB: four streams per CU fit in 160 KiB)
 constexpr uint32_t kTokRing = 2048;
 constexpr uint32_t kDpWaves = 4;          // parse wavefronts per stream the advanced parser can use (csc_kernels_dp2.inc)
+constexpr uint32_t kDpChainWaves = 8;     // chain wavefront + seven workers (csc_kernels_dp3.inc): launches with few streams
 // Advanced parser on two parse wavefronts (csc_kernels_dp2.inc): what the wavefront that visited DP node k leaves for the
 // visitor of node k + 1, and the control words of a DP window.
 struct DpEdge {
@@ -73,6 +74,7 @@ struct DpShared {
     uint32_t bstat[2];
     DpEdge e[2];               // mailbox of node k at [k & 1]
     uint16_t st_lit[64], st_p1[64];   // per coder state: price of the literal flag / of the rep0len1 flags, while a window is open
+    uint32_t e2[4][8];         // chain variant: node k's length-2 edge at [k & 3] (price, label, state, rep distances; [7] = k + 1 when written)
     uint32_t er[4][8];         // rep distances [0..3] and coder state [4] of node k at [k & 3], published as soon as its label is final
 };
 struct EncLds {
@@ -80,9 +82,12 @@ struct EncLds {
     uint16_t p2b[512];                        // probability -> price (1/128 bit; at most 12 * 128)
     uint32_t len_price[32], len_price_old[32];
     uint32_t rep[4];                          // rep_dist_[4] (live)
-    uint32_t cd2[kDpWaves][32];                      // candidate distances of the position being searched: 0-3 rep, 4 HT2, 5 HT3, 6 BT head, 7.. bucket
-                                              // ([wavefront]: the advanced parser of the hash-table configurations runs two parse wavefronts)
-    uint32_t cmp_pos[16], cmp_lim[16], cmp_res[16];
+    union {
+        uint32_t cd2[kDpWaves][32];               // candidate distances of the position being searched: 0-3 rep, 4 HT2, 5 HT3, 6 BT head, 7.. bucket
+                                                  // ([wavefront]: the advanced parser of the hash-table configurations runs several parse wavefronts)
+        struct { uint32_t cd2_row0[32]; uint32_t cmp_pos[16], cmp_lim[16], cmp_res[16]; };   // wide-bucket / binary-tree configurations run one
+                                                  // wavefront: their compare scratch lies over the unused rows
+    };
     uint32_t rp42[kDpWaves][4];                     // the four rep-index prices of the position being priced ([wavefront])
     // The parser's DP nodes (APUnit, csc_lz.h:33-41) as a 256-slot ring + a per-node log.  A node is
     // relabelled only from nodes before it and only up to good_len - 1 <= 254 positions ahead, so
@@ -627,6 +632,7 @@ DEV void compress_rle(Sc &c, const gu8 *src, uint32_t size)
 #include "csc_kernels_mf.inc"
 #include "csc_kernels_lz.inc"
 #include "csc_kernels_dp2.inc"
+#include "csc_kernels_dp3.inc"
 #include "csc_kernels_blocks.inc"
 
 }  // namespace cscmi
