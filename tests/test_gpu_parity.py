@@ -111,9 +111,10 @@ def test_config5_geometry_roundtrip_and_parity(prod, orc, zalloc):
 
 
 def test_advanced_parser_wavefront_counts(prod, orc, zalloc):
-    """The advanced parser of the hash-table levels runs 4 parse wavefronts per stream while a launch carries <= 512
-    streams (one workgroup a CU up to 256 streams, the 256-VGPR instance with two workgroups a CU beyond) and 1 above that.
-    Same bytes in every case: batches of 3, 300 and 520 small task streams (mixed text / exe, ragged sizes, some empty)
+    """The advanced parser of the hash-table levels picks its form by how many streams a launch carries: <= 128 the chain form
+    (eight wavefronts: chain + seven workers, csc_kernels_dp3.inc), <= 256 four parse wavefronts taking nodes in turn
+    (csc_kernels_dp2.inc), <= 512 the same in the 256-VGPR instance (two workgroups a CU), above that one wavefront.
+    Same bytes in every case: batches of 3, 200, 300 and 520 small task streams (mixed text / exe, ragged sizes, some empty)
     against the oracle, at levels 3 and 4."""
     import torch
     from csc_amd import corpus
@@ -121,7 +122,7 @@ def test_advanced_parser_wavefront_counts(prod, orc, zalloc):
     L = prod.lib
     L.CSCMI_EncodeDeviceChunkBatch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     want = {}
-    for count, level in ((3, 3), (300, 3), (520, 4), (300, 4)):
+    for count, level in ((3, 3), (200, 3), (300, 3), (520, 4), (300, 4), (100, 4)):
         datas = []
         for i in range(count):
             n = 0 if i % 97 == 96 else 9000 + (i * 7919) % 30000
