@@ -2,33 +2,45 @@
 """bench.py -- encode MB/s of the MI355X-native libcsc path on BASELINE.json's headline workload.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
-Workload: the enwik9 stand-in (csc_amd/corpus.py, kind "text", seed 0xC5C00002, 10^9 bytes) at
-`-m3 -d64m`.  N = 1 is BASELINE.json configs[1] (one libcsc stream: HT6 match finder + advanced
-parser).  N > 1 is configs[3]: the archiver's single-file `-pN` split (csarc.cpp:532-543), task r on
-rank r, one process per GPU -- tasks are independent streams, so there is NO data-path collective;
-torch.distributed (RCCL) only carries the barrier and the max-over-ranks time.  A "step" is one
-raw_blocksize (2 MiB) chunk = one CSCEncoder::Compress call (csc_enc.cpp:170-181) per rank, with the
-chunk already resident in HBM (CSCMI_EncodeDeviceChunk).  Weak scaling: per-GPU work is fixed.
+N = 1  BASELINE.json configs[1]: the enwik9 stand-in (csc_amd/corpus.py "enwik9": kind text, seed 0xC5C00002, 10^9 bytes;
+       the real file when $CSC_CORPUS_DIR/enwik9 exists) as ONE libcsc stream at `-m3 -d64m` (HT6 match finder + advanced
+       parser).  A step is one raw_blocksize (2 MiB) chunk = one CSCEncoder::Compress call (csc_enc.cpp:170-181) with the
+       chunk already resident in HBM (CSCMI_EncodeDeviceChunk).  `value` covers chunks W .. W+K-1; `steady` repeats the
+       measurement after the 64 MiB window has filled (chunks >= 32).
+N > 1  configs[3]: the archiver's `-p8` split of the same file (csarc.cpp:532-543) -- the SAME eight tasks at every N, dealt
+       largest first, task i of the dispatch order -> rank i mod N (csarc.cpp:355), one process per GPU.  A step advances every
+       task of the rank by one chunk with ONE launch (CSCMI_EncodeDeviceChunkBatch: one workgroup per stream).  Tasks are
+       independent streams, so there is NO data-path collective; torch.distributed (RCCL) carries the barrier, the
+       max-over-ranks time and -- outside the timed region -- the per-task digests and the hand-over of the streams to rank 0.
+       Total work is the same at every N ("scaling": "strong"), and so is `ratio`.  `--split 127` gives the second curve
+       (16 tasks per GPU at N = 8).  When launched plainly (`python bench.py --gpus N`, no RANK in the environment) the
+       script starts its N ranks itself: `python -m torch.distributed.run` as a CHILD process, before anything here has
+       touched the GPU, and relays rank 0's JSON line.
 
-One JSON line on rank 0: the contract fields + `roofline` (dominant kernel k_encode_runs against the
-8 TB/s HBM peak, algorithmic bytes per SURVEY.md section 8d) + `cpu_baseline` (the reference built as
-oracle/_ref -- or the oracle port -- timed on this box's host cores over a bounded sample).
+One JSON line on rank 0: the contract fields + `roofline` (dominant kernel k_encode_runs* against the 8 TB/s HBM peak,
+algorithmic bytes per SURVEY.md section 8d) + `cpu_baseline` (the reference built as oracle/_ref -- or the oracle port --
+timed on this box's host cores over a bounded sample; N = 1 only).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TOTAL = 10 ** 9                     # enwik9
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
 ALG_BYTES = {1: 33.0, 2: 96.0, 3: 42.0, 4: 96.0}   # SURVEY.md section 8(d): B_HT(w) per input byte (+ ratio r)
+CONFIGS = {   # BASELINE.json configs -> (corpus name, level, dict)
+    "enwik9": ("enwik9", 3, "64m"),
+    "silesia": ("silesia.tar", 5, "256m"),
+    "mix5": ("mix5", 2, "1024m"),
+}
 
 
 class CSCMIStats(C.Structure):
@@ -49,7 +61,37 @@ def parse_size(s):
     return int(s) * mul
 
 
-def cpu_baseline(data, level, dict_size, task_size, sample_bytes):
+def alg_bytes(level, ratio, stats=None):
+    """algorithmic bytes per input byte of the LZ pass"""
+    if level == 5:
+        cbar = (stats.bt_steps / max(1, stats.find_match_calls + stats.slide_positions)) if stats else 4.6
+        return 41.0 + 13.0 * cbar + ratio
+    return ALG_BYTES.get(level, 42.0) + ratio
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child torchrun (this process has not imported
+    torch or touched HIP) and relay rank 0's line.  Never exec: the box refuses an exec from a process that initialised the GPU."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    for l in p.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if p.returncode != 0 or not lines:
+        print(f"bench.py: the {n}-rank child failed (rc={p.returncode})", file=sys.stderr)
+        sys.exit(p.returncode or 1)
+    print(lines[-1], flush=True)
+    sys.exit(0)
+
+
+def cpu_baseline(data, level, dict_size, task_size):
     """the reference's own encoder (oracle/_ref) -- or the oracle port -- on this box's host cores"""
     from csc_amd.capi import CscLib
     ref_path = os.path.join(ROOT, "oracle", "_ref", "libcsc_ref.so")
@@ -62,21 +104,19 @@ def cpu_baseline(data, level, dict_size, task_size, sample_bytes):
         o.orc_zero_alloc.restype = C.c_void_p
         za = o.orc_zero_alloc()      # deterministic flush byte
     props = lib.props_init(min(dict_size, task_size), level)
-    sample = data[:sample_bytes]
     t0 = time.perf_counter()
-    rc, stream = lib.encode(sample, props=props, alloc=za)
+    rc, stream = lib.encode(data, props=props, alloc=za)
     dt = time.perf_counter() - t0
     assert rc == 0
-    return {"value": round(len(sample) / 1e6 / dt, 3), "unit": "MB/s", "cores": 1, "kind": kind,
-            "sample": f"first {len(sample)} bytes of the same stream, same CSCProps, 1 thread, "
+    return {"value": round(len(data) / 1e6 / dt, 3), "unit": "MB/s", "cores": 1, "kind": kind,
+            "sample": f"first {len(data)} bytes of the same stream, same CSCProps, 1 thread, "
                       f"{'oracle/_ref (reference sources, g++ -O4)' if kind == 'reference' else 'oracle/liborc.so (C port)'}",
-            "seconds": round(dt, 2), "ratio": round(len(stream) / max(1, len(sample)), 4)}, stream
+            "seconds": round(dt, 2), "ratio": round(len(stream) / max(1, len(data)), 4)}, stream
 
 
 def decode_all(lib, streams, whole, slices, width=256):
     """decode every task stream with CSCMI_DecodeBatch (waves of `width` handles) and compare with the input"""
     import numpy as np
-    import torch
     from csc_amd.capi import BytesReader, BytesWriter, CSC_PROP_SIZE
     L = lib.lib
     L.CSCMI_DecodeBatch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
@@ -110,22 +150,28 @@ def decode_all(lib, streams, whole, slices, width=256):
             "what": f"the same task streams decoded by CSCMI_DecodeBatch, {min(width, len(streams))} per launch, incl. compare"}
 
 
-def multi_stream_job(lib, stream_counts, level, dict_size):
+def golden(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", name)))
+    except (OSError, ValueError):
+        return None
+
+
+def multi_stream_job(lib, src, stream_counts, level, dict_size):
     """Secondary measurement (extra `multi_stream` field of the JSON line, never `value`): the archiver's
     task split is where this path shards, so one GPU can run every task of `csarc a -m3 -d64m -p<S>` at
     once -- one workgroup per task through CSCMI_EncodeDeviceChunkBatch.  Each entry encodes the WHOLE
-    10^9-byte stand-in.  S = 127 is the largest -p the reference CLI accepts for one file (u8 nfrags)."""
-    import hashlib
+    file.  S = 127 is the largest -p the reference CLI accepts for one file (u8 nfrags)."""
     import torch
     from csc_amd import corpus
     from csc_amd.capi import BytesWriter
     L = lib.lib
-    L.CSCMI_EncodeDeviceChunkBatch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
-    whole = torch.from_numpy(corpus.fill("text", corpus.SEED_ENWIK9, 0, TOTAL)).cuda()
+    total_size = src.size
+    whole = torch.from_numpy(src.read(0, total_size)).cuda()
     chunk = 2 << 20
     results = []
     for S in stream_counts:
-        slices = corpus.task_slices(TOTAL, S)
+        slices = corpus.task_slices(total_size, S)
         S = len(slices)
         hs, ws = [], []
         for off, n in slices:
@@ -160,80 +206,129 @@ def multi_stream_job(lib, stream_counts, level, dict_size):
             L.CSCEnc_Destroy(h)
         # and back: every task stream through the HIP decoder, 256 streams per launch (one per CU), checked byte for byte
         dec = decode_all(lib, [bytes(w.out) for w in ws], whole, slices)
-        balg = ALG_BYTES.get(level, 42.0) + out / total
+        balg = alg_bytes(level, out / total)
         # what the REFERENCE produces for this split (tests/golden/multi_stream_digests.json, recorded by
         # tools/make_golden_multi.py from oracle/_ref): the whole 10^9 bytes, bit for bit
         bit_exact = None
-        try:
-            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "multi_stream_digests.json")))
-            if gold["level"] == level and gold["dict"] == dict_size and str(S) in gold["splits"]:
-                bit_exact = bool(gold["splits"][str(S)]["sha256_of_stream_sha256s"] == digest)
-        except (OSError, ValueError, KeyError):
-            pass
-        results.append({"what": f"whole enwik9 stand-in (10^9 B) as csarc -m{level} -d64m -p{S}: {S} independent task streams, one workgroup each, 1 GPU",
+        gold = golden("multi_stream_digests.json")
+        if src.synthetic and gold and gold["level"] == level and gold["dict"] == dict_size and str(S) in gold["splits"]:
+            bit_exact = bool(gold["splits"][str(S)]["sha256_of_stream_sha256s"] == digest)
+        results.append({"what": f"whole {src.name} ({total_size} B) as csarc -m{level} -d{dict_size >> 20}m -p{S}: {S} independent task streams, one workgroup each, 1 GPU",
                         "value": round(total / 1e6 / dt, 3), "unit": "MB/s", "seconds": round(dt, 2), "ratio": round(out / total, 4),
                         "streams": S, "batch_launches": k, "hbm_roofline_frac": round(balg * total / dt / 1e9 / HBM_PEAK_GBS, 8),
                         "sha256_of_stream_sha256s": digest, "bit_exact_vs_reference_digest": bit_exact, "decode": dec})
     return {"multi_stream": results}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--level", type=int, default=3)
-    ap.add_argument("--dict", default="64m")
-    ap.add_argument("--cpu-sample-mib", type=int, default=48)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-exchange", action="store_true",
-                    help="N > 1: skip the RCCL hand-over of the encoded streams to rank 0 (outside the timed region)")
-    ap.add_argument("--multi-streams", default="127,954",
-                    help="extra (N=1 only): the WHOLE 10^9-byte file as -p<S> task splits, all tasks concurrently on this GPU; '' = skip")
-    args = ap.parse_args()
+def traffic_from_profile(key, bytes_per_launch):
+    """HBM bytes per launch from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc runs; counters
+    cannot be read from inside the process).  Only used when the passes were recorded for the kernel code this run loaded."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        ent = pmc.get(key)
+        so = hashlib.sha256(open(os.path.join(ROOT, "csc_amd", "libcsc_mi355x.so"), "rb").read()).hexdigest()[:16]
+        if not ent:
+            return None, "no PMC measurement committed for this configuration"
+        if ent.get("library_sha256_16") != so:
+            return None, f"profiles/pmc_traffic.json was recorded for another build of the kernels ({ent.get('library_sha256_16')} != {so}): stale, not reported"
+        return (round((ent["fetch_bytes_per_input_byte"] + ent["write_bytes_per_input_byte"]) * bytes_per_launch), ent["source"])
+    except (OSError, ValueError, KeyError) as e:
+        return None, f"no usable PMC measurement ({e!r})"
 
-    import numpy as np
-    import torch
-    import csc_amd
-    from csc_amd import corpus
+
+class Rank:
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+        # CSC_BENCH_BACKEND=gloo (tests only): the N > 1 code path with several ranks sharing one GPU; the driver's runs use RCCL
+        self.backend = os.environ.get("CSC_BENCH_BACKEND", "nccl")
+        dev = local_rank if self.backend == "nccl" else local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if self.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+            else:
+                dist.init_process_group(backend=self.backend)
+        self.red_dev = "cuda" if self.backend == "nccl" else "cpu"
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def reduce(self, x, op):
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.red_dev)
+        if self.dist:
+            self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
+        return float(t.item())
+
+    def gather_objects(self, obj):
+        if not self.dist:
+            return [obj]
+        box = [None] * self.world
+        self.dist.all_gather_object(box, obj)
+        return box
+
+    def done(self):
+        if self.dist:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def base_line(args, R, src, level, value, tsec, scaling, workload, props, ratio):
+    return {
+        "metric": f"encode MB/s (10^6 input bytes / wall-clock) on {src.name}{'' if not src.synthetic else ' stand-in'}, -m{level} -d{args.dict}; stream bit-exact vs reference",
+        "value": round(value, 4), "unit": "MB/s",
+        "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(tsec * 1e3 / max(1, args.steps), 3),
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "u8/u32 (byte + 32-bit integer work; 12-bit probabilities, 64-bit range-coder low)",
+        "data": src.label,
+        "config": {"workload": workload,
+                   "dict_size": int(props.dict_size), "hash_bits": int(props.hash_bits), "hash_width": int(props.hash_width),
+                   "good_len": int(props.good_len), "lz_mode": int(props.lz_mode), "bt_size": int(props.bt_size)},
+        "ratio": round(ratio, 4),
+    }
+
+
+def roofline(level, ratio, launches, kern_ms, in_b, kernel, note, traffic=(None, None), stats=None):
+    balg = alg_bytes(level, ratio, stats)
+    avg_ms = kern_ms / max(1, launches)
+    bpl = in_b / max(1, launches)
+    achieved = balg * bpl / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    return {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic[0], "traffic_note": traffic[1],
+            "kernel": kernel, "launches": int(launches), "avg_launch_ms": round(avg_ms, 3),
+            "alg_bytes_per_input_byte": round(balg, 3), "input_bytes_per_launch": round(bpl, 1), "note": note}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def run_single(args, R, lib, src, level, dict_size):
+    """N = 1: one libcsc stream (BASELINE configs[1] by default)"""
+    torch = R.torch
     from csc_amd.capi import BytesWriter
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    # CSC_BENCH_BACKEND=gloo (tests only): the N > 1 code path with several ranks sharing one GPU; the driver's runs use RCCL
-    backend = os.environ.get("CSC_BENCH_BACKEND", "nccl")
-    local_dev = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_dev)
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_dev))
-        else:
-            dist.init_process_group(backend=backend)
-    red_dev = "cuda" if backend == "nccl" else "cpu"
-
-    level, dict_size = args.level, parse_size(args.dict)
-    lib = csc_amd.load()
     L = lib.lib
-    L.CSCMI_EncodeDeviceChunk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
-    L.CSCMI_EncodeDeviceChunk.restype = C.c_int
-    L.CSCMI_GetStats.argtypes = [C.c_void_p, C.POINTER(CSCMIStats)]
-
-    # this rank's task = slice `rank` of the -p{world} split of the 10^9-byte file
-    slices = corpus.task_slices(TOTAL, world)
-    off, task_size = slices[rank % len(slices)]
+    task_size = src.size
     props = lib.props_init(min(dict_size, task_size), level)          # csa_worker.cpp:35
     chunk = int(props.raw_blocksize)
     nsteps = args.warmup + args.steps
-    nbytes = min(task_size, nsteps * chunk)
-    host = corpus.fill("text", corpus.SEED_ENWIK9, off, nbytes)
+    steady_from = max(nsteps, (int(props.dict_size) + chunk - 1) // chunk) if args.steady_steps > 0 else nsteps
+    nchunks = steady_from + (args.steady_steps if args.steady_steps > 0 else 0)
+    nbytes = min(task_size, nchunks * chunk)
+    host = src.read(0, nbytes)
     dev = torch.from_numpy(host).cuda()                                # inputs resident in HBM
     torch.cuda.synchronize()
-
     writer = BytesWriter()
     h = L.CSCEnc_Create(C.byref(props), C.cast(writer.ptr(), C.c_void_p), None)
     if not h:
@@ -242,128 +337,255 @@ def main():
 
     def step(i):
         n = min(chunk, nbytes - i * chunk)
+        if n <= 0:
+            return 0
         rc = L.CSCMI_EncodeDeviceChunk(h, C.c_void_p(dev.data_ptr() + i * chunk), n)
         if rc != 0:
             raise SystemExit(f"encode failed rc={rc}")
         return n
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def stats():
+        s = CSCMIStats()
+        L.CSCMI_GetStats(h, C.byref(s))
+        return s
+
+    def region(a, b):
+        s0 = stats()
+        R.barrier()
+        t0 = time.perf_counter()
+        nb = 0
+        for i in range(a, b):
+            nb += step(i)
+        R.barrier()
+        dt = time.perf_counter() - t0
+        return nb, dt, s0, stats()
 
     for i in range(args.warmup):
         step(i)
-    s0 = CSCMIStats()
-    L.CSCMI_GetStats(h, C.byref(s0))
-    barrier()
-    t0 = time.perf_counter()
-    timed_bytes = 0
-    for i in range(args.warmup, nsteps):
-        timed_bytes += step(i)
-    barrier()
-    dt = time.perf_counter() - t0
-    s1 = CSCMIStats()
-    L.CSCMI_GetStats(h, C.byref(s1))
+    timed_bytes, dt, s0, s1 = region(args.warmup, nsteps)
     gpu_stream = bytes(writer.out)       # header + every finished chunk (no EOF yet): a prefix of the full stream
+    launches = s1.encode_launches - s0.encode_launches
+    kern_ms = s1.encode_kernel_ms - s0.encode_kernel_ms
+    in_b, out_b = s1.input_bytes - s0.input_bytes, s1.output_bytes - s0.output_bytes
+    ratio = out_b / max(1, in_b)
+    line = base_line(args, R, src, level, timed_bytes / 1e6 / dt, dt, "weak",
+                     f"{src.name} {src.size} B, -m{level} -d{args.dict} single stream"
+                     + (" (BASELINE.json configs[1])" if args.config == "enwik9" else f" (BASELINE.json config '{args.config}')")
+                     + f"; step = one {chunk}-byte chunk (CSCEncoder::Compress), input resident in HBM; timed chunks {args.warmup}..{nsteps - 1}",
+                     props, ratio)
+    ds = CSCMIStats()
+    for f, _ in CSCMIStats._fields_:
+        setattr(ds, f, getattr(s1, f) - getattr(s0, f))
+    bpl = in_b / max(1, launches)
+    line["roofline"] = roofline(level, ratio, launches, kern_ms, in_b, "k_encode_runs",
+                                "one stream = one workgroup: the libcsc chain is latency/issue-bound, not bandwidth-bound",
+                                traffic_from_profile(f"m{level}_d{args.dict}_single_stream", bpl), ds)
+    line["counters"] = {"find_match_calls": int(ds.find_match_calls), "slide_positions": int(ds.slide_positions),
+                        "bt_steps": int(ds.bt_steps), "literals": int(ds.literals), "matches": int(ds.matches),
+                        "analyze_kernel_ms": round(ds.analyze_kernel_ms, 3)}
+    # the same stream once the window is full (chunks >= dict/chunk): what the 10^9-byte job runs at for most of its length
+    if args.steady_steps > 0 and steady_from * chunk < nbytes:
+        for i in range(nsteps, steady_from):
+            step(i)
+        sb, sdt, t0, t1 = region(steady_from, nchunks)
+        sl, sk = t1.encode_launches - t0.encode_launches, t1.encode_kernel_ms - t0.encode_kernel_ms
+        sr = (t1.output_bytes - t0.output_bytes) / max(1, t1.input_bytes - t0.input_bytes)
+        line["steady"] = {"what": f"same stream, chunks {steady_from}..{nchunks - 1}: the {int(props.dict_size) >> 20} MiB window is full and wraps",
+                          "value": round(sb / 1e6 / sdt, 4), "unit": "MB/s", "ratio": round(sr, 4),
+                          "roofline_frac": round(alg_bytes(level, sr) * (t1.input_bytes - t0.input_bytes) / max(1e-9, sk * 1e-3) / 1e9 / HBM_PEAK_GBS, 8),
+                          "avg_launch_ms": round(sk / max(1, sl), 3)}
+        gpu_stream = bytes(writer.out)
+    if not args.no_cpu_baseline:
+        sample = max(nbytes, args.cpu_sample_mib << 20)
+        cpu_in = src.read(0, min(task_size, sample)).tobytes()
+        base, cpu_stream = cpu_baseline(cpu_in, level, dict_size, task_size)
+        line["cpu_baseline"] = base
+        line["bit_exact_vs_cpu_baseline"] = bool(cpu_stream[:len(gpu_stream)] == gpu_stream)
+    else:
+        line["cpu_baseline"] = None
+    L.CSCEnc_Encode_Flush(h)
+    L.CSCEnc_Destroy(h)
+    return line
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-    tot_bytes = torch.tensor([float(timed_bytes)], dtype=torch.float64, device=red_dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot_bytes, op=dist.ReduceOp.SUM)
-    tmax, tot_bytes = float(tmax.item()), float(tot_bytes.item())
 
-    # N > 1, outside the timed region: the one exchange of the sharded archiver (csc_amd/sharded.py) --
-    # every rank's encoded stream so far goes to rank 0 as a device tensor over RCCL, rank 0 checks the digests
+def run_split(args, R, lib, src, level, dict_size, split, steps, warmup):
+    """the archiver's -p<split> tasks of the file, dealt over the ranks; one batch launch per step and rank"""
+    torch = R.torch
+    from csc_amd import corpus, tasks
+    from csc_amd.capi import BytesWriter
+    L = lib.lib
+    slices = corpus.task_slices(src.size, split)
+    mine = tasks.assign(slices, R.world)[R.rank]                     # dispatch order (largest first), i mod N
+    chunk = 2 << 20
+    nsteps = warmup + steps
+    hs, ws, devs, sizes = [], [], [], []
+    for tid in mine:
+        off, n = slices[tid]
+        props = lib.props_init(min(dict_size, n), level)
+        chunk = int(props.raw_blocksize)
+        w = BytesWriter()
+        h = L.CSCEnc_Create(C.byref(props), C.cast(w.ptr(), C.c_void_p), None)
+        if not h:
+            raise SystemExit("CSCEnc_Create failed")
+        w.out += lib.write_properties(props)
+        nb = min(n, nsteps * chunk)
+        hs.append(h); ws.append(w); sizes.append(nb)
+        devs.append(torch.from_numpy(src.read(off, nb)).cuda())
+    S = len(hs)
+    H = (C.c_void_p * max(1, S))(*hs)
+    torch.cuda.synchronize()
+
+    def step(i):
+        Z = [max(0, min(chunk, nb - i * chunk)) for nb in sizes]
+        if S == 0 or not any(Z):
+            return 0
+        P = (C.c_void_p * S)(*[d.data_ptr() + i * chunk for d in devs])
+        rc = L.CSCMI_EncodeDeviceChunkBatch(S, H, P, (C.c_size_t * S)(*Z))
+        if rc != 0:
+            raise SystemExit(f"batch encode failed rc={rc}")
+        return sum(Z)
+
+    def stats_sum():
+        tot = CSCMIStats()
+        for h in hs:
+            s = CSCMIStats()
+            L.CSCMI_GetStats(h, C.byref(s))
+            for f, _ in CSCMIStats._fields_:
+                setattr(tot, f, getattr(tot, f) + getattr(s, f))
+        return tot
+
+    for i in range(warmup):
+        step(i)
+    s0 = stats_sum()
+    R.barrier()
+    t0 = time.perf_counter()
+    timed = 0
+    for i in range(warmup, nsteps):
+        timed += step(i)
+    R.barrier()
+    dt = time.perf_counter() - t0
+    s1 = stats_sum()
+    tmax = R.reduce(dt, "MAX")
+    tot_bytes = R.reduce(timed, "SUM")
+    in_b = R.reduce(s1.input_bytes - s0.input_bytes, "SUM")
+    out_b = R.reduce(s1.output_bytes - s0.output_bytes, "SUM")
+    # per-task check against what the REFERENCE wrote for the same task (tests/golden/split_prefix_digests.json, recorded by
+    # tools/make_golden_prefix.py from oracle/_ref): the stream after c chunks is a prefix of the task's stream
+    gold = golden("split_prefix_digests.json")
+    recs = {}
+    for tid, w, nb in zip(mine, ws, sizes):
+        done = (min(nb, nsteps * chunk) + chunk - 1) // chunk
+        s = bytes(w.out)
+        rec = {"chunks": done, "stream_bytes": len(s), "sha256": hashlib.sha256(s).hexdigest(), "rank": R.rank}
+        g = None
+        if gold and src.synthetic and gold["level"] == level and gold["dict"] == dict_size:
+            g = gold["splits"].get(str(len(slices)), {}).get(str(tid), {}).get(str(done))
+        rec["bit_exact_vs_reference"] = None if g is None else bool(g["sha256"] == rec["sha256"] and g["stream_bytes"] == rec["stream_bytes"])
+        recs[tid] = rec
+    merged = {}
+    for part in R.gather_objects(recs):
+        merged.update(part)
+    # N > 1, outside the timed region: the one exchange of the sharded archiver (csc_amd/sharded.py, SURVEY 8e) -- every rank's
+    # encoded streams so far go to rank 0 as a device tensor over RCCL, rank 0 checks the digests
     exchange = None
-    if world > 1 and not args.no_exchange:
+    if R.world > 1 and not args.no_exchange:
         try:
-            import hashlib
             from csc_amd import sharded
-            meta = [None] * world
-            dist.all_gather_object(meta, (len(gpu_stream), hashlib.sha256(gpu_stream).hexdigest()))
-            barrier()
+            blob = b"".join(bytes(w.out) for w in ws)
+            meta = R.gather_objects((len(blob), hashlib.sha256(blob).hexdigest()))
+            R.barrier()
             te = time.perf_counter()
-            got = sharded.gather_blobs(gpu_stream, 0)
-            barrier()
+            got = sharded.gather_blobs(blob, 0)
+            R.barrier()
             te = time.perf_counter() - te
-            if rank == 0:
-                ok = all(len(got[r]) == meta[r][0] and hashlib.sha256(got[r]).hexdigest() == meta[r][1] for r in range(world))
+            if R.rank == 0:
+                ok = all(len(got[r]) == meta[r][0] and hashlib.sha256(got[r]).hexdigest() == meta[r][1] for r in range(R.world))
                 exchange = {"what": "encoded task streams of all ranks -> rank 0 (all_gather of lengths + grouped RCCL send/recv of device tensors)",
                             "ok": bool(ok), "bytes": int(sum(m[0] for m in meta)), "seconds": round(te, 4)}
         except Exception as e:      # never lose the bench line to the hand-over
             exchange = {"ok": False, "error": repr(e)[:300]}
-
-    if rank == 0:
-        launches = s1.encode_launches - s0.encode_launches
-        kern_ms = s1.encode_kernel_ms - s0.encode_kernel_ms
-        in_b = s1.input_bytes - s0.input_bytes
-        out_b = s1.output_bytes - s0.output_bytes
-        ratio = out_b / max(1, in_b)
-        balg = ALG_BYTES.get(level, 42.0) + ratio
-        avg_ms = kern_ms / max(1, launches)
-        bytes_per_launch = in_b / max(1, launches)
-        achieved = balg * bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM bytes per launch from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc runs of this very
-        # command; counters cannot be read from inside the process).  The committed measurement is scaled by input bytes.
-        traffic, traffic_note = None, "no PMC measurement committed for this configuration"
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            ent = pmc.get(f"m{level}_d{args.dict}_single_stream")
-            if ent and world == 1:
-                traffic = round((ent["fetch_bytes_per_input_byte"] + ent["write_bytes_per_input_byte"]) * bytes_per_launch)
-                traffic_note = ent["source"]
-        except (OSError, ValueError, KeyError):
-            pass
-        line = {
-            "metric": "encode MB/s (10^6 input bytes / wall-clock) on the enwik9 stand-in, -m3 -d64m; stream bit-exact vs reference",
-            "value": round(tot_bytes / 1e6 / tmax, 4),
-            "unit": "MB/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(tmax * 1e3 / max(1, args.steps), 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/u32 (byte + 32-bit integer work; 12-bit probabilities, 64-bit range-coder low)",
-            "data": "synthetic (seeded enwik9 stand-in, csc_amd/csrc/corpus.c kind=text seed=0xC5C00002)",
-            "config": {"workload": f"enwik9-like 10^9 B, -m{level} -d{args.dict}"
-                                   + (f" -p{world}: task r on GPU r (csarc.cpp:532-543), independent streams" if world > 1
-                                      else " single stream (BASELINE.json configs[1])"),
-                       "step": f"one {chunk}-byte chunk (CSCEncoder::Compress) per rank, input resident in HBM",
-                       "dict_size": int(props.dict_size), "hash_bits": int(props.hash_bits),
-                       "hash_width": int(props.hash_width), "good_len": int(props.good_len), "lz_mode": int(props.lz_mode)},
-            "ratio": round(ratio, 4),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": "k_encode_runs", "launches": int(launches),
-                         "avg_launch_ms": round(avg_ms, 3), "alg_bytes_per_input_byte": round(balg, 3),
-                         "input_bytes_per_launch": round(bytes_per_launch, 1),
-                         "note": "one stream = one workgroup of up to four parse wavefronts: the libcsc chain is latency/issue-bound, not bandwidth-bound"},
-            "counters": {"find_match_calls": int(s1.find_match_calls - s0.find_match_calls),
-                         "slide_positions": int(s1.slide_positions - s0.slide_positions),
-                         "literals": int(s1.literals - s0.literals), "matches": int(s1.matches - s0.matches),
-                         "analyze_kernel_ms": round(s1.analyze_kernel_ms - s0.analyze_kernel_ms, 3)},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            sample = max(nbytes, args.cpu_sample_mib << 20)
-            cpu_in = corpus.fill("text", corpus.SEED_ENWIK9, off, min(task_size, sample)).tobytes()
-            base, cpu_stream = cpu_baseline(cpu_in, level, dict_size, task_size, len(cpu_in))
-            line["cpu_baseline"] = base
-            line["bit_exact_vs_cpu_baseline"] = bool(cpu_stream[:len(gpu_stream)] == gpu_stream)
-        else:
-            line["cpu_baseline"] = None
+    line = None
+    if R.rank == 0:
+        ratio = out_b / max(1.0, in_b)
+        props = lib.props_init(min(dict_size, slices[0][1]), level)
+        line = base_line(args, R, src, level, tot_bytes / 1e6 / tmax, tmax, "strong",
+                         f"{src.name} {src.size} B, -m{level} -d{args.dict} -p{split}: the same {len(slices)} tasks at every N (csarc.cpp:532-543), "
+                         f"dealt largest first, task i -> rank i mod N (csarc.cpp:355); step = one {chunk}-byte chunk of every task of the rank, "
+                         f"ONE launch per rank (one workgroup per stream), inputs resident in HBM; timed chunks {warmup}..{nsteps - 1} of every task",
+                         props, ratio)
+        line["steps"], line["warmup"] = steps, warmup
+        line["ms_per_step"] = round(tmax * 1e3 / max(1, steps), 3)
+        # launch count and HIP-event kernel time accrue on the batch's lead handle only, so the sums are the lead's
+        line["roofline"] = roofline(level, ratio, s1.encode_launches - s0.encode_launches, s1.encode_kernel_ms - s0.encode_kernel_ms,
+                                    (s1.input_bytes - s0.input_bytes), "k_encode_runs_multi*",
+                                    f"rank 0's GPU: {S} streams per launch, one workgroup each; per-launch time from HIP events on the launch stream")
+        line["tasks_per_rank"] = [len(a) for a in tasks.assign(slices, R.world)]
+        line["tasks"] = [dict(task=t, **merged[t]) for t in sorted(merged)]
+        ex = [r["bit_exact_vs_reference"] for r in merged.values()]
+        line["bit_exact_vs_reference"] = None if any(e is None for e in ex) else bool(all(ex))
+        line["cpu_baseline"] = None
         if exchange is not None:
             line["exchange"] = exchange
-    L.CSCEnc_Encode_Flush(h)
-    L.CSCEnc_Destroy(h)
-    if rank == 0:
-        if world == 1 and args.multi_streams:
-            # extra field, not `value`: every task of the -p<S> split at once on this one GPU
-            line.update(multi_stream_job(lib, [int(x) for x in args.multi_streams.split(",")], level, dict_size))
+    for h in hs:
+        L.CSCEnc_Encode_Flush(h)
+        L.CSCEnc_Destroy(h)
+    return line
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="enwik9", choices=sorted(CONFIGS), help="which BASELINE.json workload (N = 1): enwik9 -m3 -d64m (headline), silesia -m5 -d256m, mix5 -m2 -d1024m")
+    ap.add_argument("--level", type=int, default=None)
+    ap.add_argument("--dict", default=None)
+    ap.add_argument("--split", type=int, default=0, help="task split: 0 = one stream at N = 1, -p8 at N > 1; S > 0 = the -p<S> tasks of the file at any N")
+    ap.add_argument("--steady-steps", type=int, default=3, help="N = 1 single stream: also time this many chunks after the window has filled (0 = skip)")
+    ap.add_argument("--cpu-sample-mib", type=int, default=48)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exchange", action="store_true",
+                    help="N > 1: skip the RCCL hand-over of the encoded streams to rank 0 (outside the timed region)")
+    ap.add_argument("--multi-streams", default="127,954",
+                    help="extra (N = 1, enwik9 only): the WHOLE file as -p<S> task splits, all tasks concurrently on this GPU; '' = skip")
+    ap.add_argument("--p8-steps", type=int, default=2, help="extra (N = 1, enwik9 only): the N > 1 workload (-p8) on this one GPU for this many steps; 0 = skip")
+    args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])          # does not return
+
+    name, lvl, dct = CONFIGS[args.config]
+    level = args.level if args.level is not None else lvl
+    args.dict = args.dict or dct
+    dict_size = parse_size(args.dict)
+    R = Rank(args)
+    import csc_amd
+    from csc_amd import corpus
+    lib = csc_amd.load()
+    L = lib.lib
+    L.CSCMI_EncodeDeviceChunk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.CSCMI_EncodeDeviceChunk.restype = C.c_int
+    L.CSCMI_EncodeDeviceChunkBatch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.CSCMI_EncodeDeviceChunkBatch.restype = C.c_int
+    L.CSCMI_GetStats.argtypes = [C.c_void_p, C.POINTER(CSCMIStats)]
+    src = corpus.Source(name)
+
+    split = args.split if args.split > 0 else (8 if R.world > 1 else 0)
+    if split:
+        line = run_split(args, R, lib, src, level, dict_size, split, args.steps, args.warmup)
+    else:
+        line = run_single(args, R, lib, src, level, dict_size)
+        if args.config == "enwik9" and args.level is None:
+            if args.p8_steps > 0:
+                # the point N = 1 of the -p8 curve (what --gpus 2/4/8 run), as an extra field: `value` stays configs[1]
+                p8 = run_split(args, R, lib, src, level, dict_size, 8, args.p8_steps, 1)
+                line["p8_on_one_gpu"] = {k: p8[k] for k in ("value", "unit", "ratio", "ms_per_step", "steps", "warmup", "roofline", "bit_exact_vs_reference", "tasks_per_rank")}
+                line["p8_on_one_gpu"]["what"] = p8["config"]["workload"]
+            if args.multi_streams:
+                # extra field, not `value`: every task of the -p<S> split at once on this one GPU
+                line.update(multi_stream_job(lib, src, [int(x) for x in args.multi_streams.split(",")], level, dict_size))
+    if R.rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    R.done()
 
 
 if __name__ == "__main__":

@@ -40,7 +40,11 @@ LIST_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_in
 
 SYMBOLS = ["CSA_OptionsInit", "CSA_Add", "CSA_Extract", "CSA_Test", "CSA_List", "CSA_ReadIndex",
            "CSA_Adler32", "CSAMI_Adler32Device", "CSA_DecimalTime", "CSA_UnixTime",
-           "CSAMI_AddShardEncode", "CSAMI_FreeBlob", "CSAMI_AddShardAssemble"]
+           "CSAMI_AddShardEncode", "CSAMI_FreeBlob", "CSAMI_AddShardAssemble", "CSAMI_PlanInfo", "CSA_IndexRoundTrip"]
+
+CSA_MAX_FRAGMENTS = 127
+CSA_TOO_MANY_FRAGMENTS = -94
+CSA_UNSAFE_NAME = -93
 
 _lib = None
 
@@ -76,6 +80,10 @@ def lib():
         L.CSAMI_AddShardAssemble.argtypes = [C.c_char_p, names, C.c_int, C.POINTER(CSAOptions), C.POINTER(C.c_void_p),
                                              C.POINTER(C.c_uint64), C.c_int, C.POINTER(CSAStats)]
         L.CSAMI_AddShardAssemble.restype = C.c_int
+        L.CSAMI_PlanInfo.argtypes = [names, C.c_int, C.POINTER(CSAOptions), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.CSAMI_PlanInfo.restype = C.c_int
+        L.CSA_IndexRoundTrip.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.CSA_IndexRoundTrip.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -105,6 +113,26 @@ def add(arcname: str, filenames: Sequence[str], **opts):
     arr, n = _names(filenames)
     rc = lib().CSA_Add(arcname.encode(), arr, n, C.byref(o), C.byref(st))
     return rc, st.as_dict()
+
+
+def plan_info(filenames: Sequence[str], **opts):
+    """the plan `add` would execute (host only) -> (rc, number of task streams, largest fragment count of any file)"""
+    o = options(**opts)
+    arr, n = _names(filenames)
+    nt, mf = C.c_uint32(), C.c_uint32()
+    rc = lib().CSAMI_PlanInfo(arr, n, C.byref(o), C.byref(nt), C.byref(mf))
+    return rc, int(nt.value), int(mf.value)
+
+
+def index_round_trip(raw: bytes):
+    """bounds-checked parse + re-pack of a raw index buffer -> (rc, bytes): rc = re-packed size, -1 unparsable, CSA_UNSAFE_NAME"""
+    buf = (C.c_uint8 * max(len(raw), 1)).from_buffer_copy(raw or b"\0")
+    n = lib().CSA_IndexRoundTrip(buf, len(raw), None, 0)
+    if n < 0:
+        return int(n), b""
+    out = (C.c_uint8 * max(n, 1))()
+    lib().CSA_IndexRoundTrip(buf, len(raw), out, n)
+    return int(n), bytes(out[:n])
 
 
 def add_shard_encode(filenames: Sequence[str], rank: int, world: int, **opts):

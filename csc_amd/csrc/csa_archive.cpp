@@ -42,6 +42,7 @@ constexpr uint32_t kAdlerBase = 65521;
 constexpr uint32_t kAdlerPiece = 16384;              // bytes per k_adler_pieces workgroup
 constexpr int kMaxStreams = 1024;
 constexpr int kStageBufs = 8;
+constexpr uint32_t kMaxFrags = CSA_MAX_FRAGMENTS;
 const char *const kDummyName = "****";               // csa_common.h:79
 
 double now_s()
@@ -103,7 +104,7 @@ std::vector<uint8_t> pack_index(const Index &index, const BlockIndex &abindex, c
         put_le(out, (uint64_t)e.edate, 8);
         put_le(out, (uint64_t)e.esize, 8);
         put_le(out, (uint64_t)e.eattr, 8);
-        out.push_back((uint8_t)e.frags.size());
+        out.push_back((uint8_t)std::min<size_t>(e.frags.size(), 255));   // plan_add refuses plans with more than 127
         for (const CSAFrag &f : e.frags) {
             put_le(out, f.bid, 4); put_le(out, f.checksum, 4);
             put_le(out, f.posblock, 8); put_le(out, f.size, 8); put_le(out, f.posfile, 8);
@@ -140,6 +141,7 @@ bool unpack_index(Index &index, BlockIndex &abindex, const uint8_t *buf, uint64_
         e.esize = (int64_t)load_le(buf + pos, 8); pos += 8;
         e.eattr = (int64_t)load_le(buf + pos, 8); pos += 8;
         int nfr = (int8_t)buf[pos]; pos += 1;                       // int8_t: csa_indexpack.cpp:105
+        if (nfr < 0) return false;                                  // > 127 fragments: unreadable (there too)
         for (int k = 0; k < nfr; k++) {
             if (!need(32)) return false;
             CSAFrag f;
@@ -239,13 +241,15 @@ struct MemSource {                 // MemReader, csa_io.h:428-443
 
 struct MemSink {                   // MemWriter, csa_io.h:445-460
     ISeqOutStream os;
-    std::vector<uint8_t> buf; uint64_t pos = 0;
-    explicit MemSink(uint64_t cap) : buf(cap) { os.Write = &MemSink::write_cb; }
+    std::vector<uint8_t> buf; uint64_t pos = 0, cap;
+    // `cap` comes from an archive header: the buffer grows with what is actually decoded, never beyond it
+    explicit MemSink(uint64_t cap_) : cap(cap_) { buf.reserve((size_t)std::min<uint64_t>(cap_, 1u << 20)); os.Write = &MemSink::write_cb; }
     static size_t write_cb(void *p, const void *src, size_t size)
     {
         MemSink *w = (MemSink *)p;
-        uint64_t s = std::min<uint64_t>(size, w->buf.size() - w->pos);
-        memcpy(w->buf.data() + w->pos, src, s);
+        uint64_t s = std::min<uint64_t>(size, w->cap - w->pos);
+        const uint8_t *b = (const uint8_t *)src;
+        w->buf.insert(w->buf.end(), b, b + s);
         w->pos += s;
         return s;
     }
@@ -302,10 +306,15 @@ bool ext_less(Index::iterator a, Index::iterator b)
 std::vector<Task> cap_tasks(const std::vector<Task> &in, uint64_t cap)
 {
     std::vector<Task> out;
+    // slices a file already has (the -p split): every slice adds at most one short tail piece, so pieces of at least
+    // esize / (127 - slices) bytes keep the file's total at or below 127 (plan_add refuses what still exceeds it)
+    std::map<const void *, uint64_t> slices;
+    for (const Task &t : in) for (const FilePiece &f : t.files) slices[(const void *)&*f.it]++;
     for (const Task &t : in) {
         Task cur;
         for (const FilePiece &f : t.files) {
-            const uint64_t min_piece = (f.size + 126) / 127;           // keeps the fragment count <= 127
+            const uint64_t ns = slices[(const void *)&*f.it], whole = (uint64_t)f.it->second.esize;
+            const uint64_t min_piece = ns < 127 ? (whole + (127 - ns) - 1) / (127 - ns) : whole;
             uint64_t off = f.off, left = f.size;
             if (left == 0) { cur.add(f.path, off, 0, 0, 0, f.it); continue; }
             while (left) {
@@ -331,7 +340,7 @@ std::vector<Task> plan_tasks(Index &index, int split_count)
     std::vector<Index::iterator> order;
     for (Index::iterator it = index.begin(); it != index.end(); ++it) {
         const std::string &n = it->first;
-        if (n[n.size() - 1] == '/') continue;
+        if (n.empty() || n[n.size() - 1] == '/') continue;
         order.push_back(it);
         memset(it->second.ext, 0, 4);
         size_t dot = n.find_last_of('.'), slash = n.find_last_of('/');
@@ -706,6 +715,14 @@ int read_index(const char *arcname, Index &index, BlockIndex &abindex, std::vect
     }
     uint64_t index_pos = load_le(hdr + 8, 8);
     uint32_t csize = (uint32_t)load_le(hdr + 16, 4), rsize = (uint32_t)load_le(hdr + 20, 4);
+    {
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || index_pos > (uint64_t)sb.st_size || csize > (uint64_t)sb.st_size - index_pos) {
+            fprintf(stderr, "Invalid csarc file\n");
+            close(fd);
+            return -1;
+        }
+    }
     std::vector<uint8_t> comp(csize);
     uint64_t got = 0;
     while (got < csize) {
@@ -723,7 +740,7 @@ int read_index(const char *arcname, Index &index, BlockIndex &abindex, std::vect
     if (!h) return -1;
     int rc = CSCDec_Decode(h, &sink.os, NULL);
     CSCDec_Destroy(h);
-    if (rc < 0 || sink.pos != rsize || !unpack_index(index, abindex, sink.buf.data(), rsize)) {
+    if (rc < 0 || sink.pos != rsize || sink.buf.size() != rsize || !unpack_index(index, abindex, sink.buf.data(), rsize)) {
         fprintf(stderr, "Invalid csarc file (index)\n");
         return -1;
     }
@@ -888,6 +905,21 @@ int decode_wave(int arc_fd, std::vector<Task> &tasks, size_t first, size_t count
     return worst;
 }
 
+// A stored name Extract may follow: not empty, no `..` component (with either separator).  Absolute names and drive letters are
+// re-rooted under to_dir by the reference's own rule (csarc.cpp:613-627) and stay allowed.
+bool name_is_safe(const std::string &n)
+{
+    if (n.empty()) return false;
+    size_t i = 0;
+    while (i <= n.size()) {
+        size_t j = i;
+        while (j < n.size() && n[j] != '/' && n[j] != '\\') j++;
+        if (j - i == 2 && n[i] == '.' && n[i + 1] == '.') return false;
+        i = j + 1;
+    }
+    return true;
+}
+
 // Extract / Test share everything but the output names: csarc.cpp:600-650, :667-700, decompress_mt :411-470
 int read_archive(const char *arcname, const Selection &sel, const CSAOptions &o, bool extract, CSAStats *st)
 {
@@ -900,8 +932,14 @@ int read_archive(const char *arcname, const Selection &sel, const CSAOptions &o,
     std::vector<Task> tasks;
     std::map<uint64_t, size_t> idmap;
     std::string to_dir = o.to_dir && o.to_dir[0] ? o.to_dir : "./";
+    uint32_t unsafe = 0;
     for (Index::iterator it = index.begin(); it != index.end(); ++it) {
         if (!sel.names.empty() && !sel.has(it->first.c_str())) continue;
+        if (!name_is_safe(it->first)) {
+            fprintf(stderr, "csa-mi355x: entry \"%s\" skipped: empty name or `..` component\n", it->first.c_str());
+            unsafe++;
+            continue;
+        }
         std::string out_name = kDummyName;
         if (extract) {
             out_name = it->first;                                            // csarc.cpp:613-627
@@ -975,7 +1013,7 @@ int read_archive(const char *arcname, const Selection &sel, const CSAOptions &o,
         fprintf(stderr, "Extraction error, archive corrupted\n");           // csarc.cpp:464-467
         return -1;
     }
-    return 0;
+    return unsafe ? CSA_UNSAFE_NAME : 0;
 }
 
 Selection make_selection(const char *const *names, int n)
@@ -1084,7 +1122,7 @@ struct AddPlan {
     std::vector<Task> tasks;
 };
 
-void plan_add(AddPlan &P, const char *const *filenames, int nfilenames, const CSAOptions *opt)
+int plan_add(AddPlan &P, const char *const *filenames, int nfilenames, const CSAOptions *opt)
 {
     if (opt) P.o = *opt; else CSA_OptionsInit(&P.o);
     if (P.o.split_count <= 0) P.o.split_count = 1;                           // csarc.cpp:199-200
@@ -1092,6 +1130,17 @@ void plan_add(AddPlan &P, const char *const *filenames, int nfilenames, const CS
     for (const std::string &f : sel.names) scan_path(P.index, sel, f, P.o.recurse != 0);
     P.tasks = plan_tasks(P.index, P.o.split_count);
     if (P.o.task_bytes) P.tasks = cap_tasks(P.tasks, P.o.task_bytes);
+    // the index stores a file's fragment count in one signed byte (csa_indexpack.cpp:84,105): more than 127 would write an
+    // archive nobody can read back -- refuse before anything is written
+    std::map<const void *, uint32_t> nfr;
+    for (const Task &t : P.tasks)
+        for (const FilePiece &f : t.files)
+            if (++nfr[(const void *)&*f.it] > kMaxFrags) {
+                fprintf(stderr, "csa-mi355x: %s would be stored as more than %u fragments (split_count / task_bytes too fine); nothing written\n",
+                        f.it->first.c_str(), kMaxFrags);
+                return CSA_TOO_MANY_FRAGMENTS;
+            }
+    return 0;
 }
 
 int open_archive(const char *arcname, const CSAOptions &o, int &fd)
@@ -1172,9 +1221,10 @@ int CSA_Add(const char *arcname, const char *const *filenames, int nfilenames, c
             return 1;
         }
     }
-    plan_add(P, filenames, nfilenames, opt);
+    int rc = plan_add(P, filenames, nfilenames, opt);
+    if (rc) return rc;
     int fd = -1;
-    int rc = open_archive(arcname, P.o, fd);
+    rc = open_archive(arcname, P.o, fd);
     if (rc) return rc;
     uint64_t arc_end = kHeaderSize;
     BlockIndex abindex;
@@ -1197,7 +1247,7 @@ int CSAMI_AddShardEncode(const char *const *filenames, int nfilenames, const CSA
     *blob = nullptr; *blob_len = 0;
     if (CSCMI_DeviceCheck() != 0) return CSCMI_DEVICE_ERROR;
     AddPlan P;
-    plan_add(P, filenames, nfilenames, opt);
+    if (int prc = plan_add(P, filenames, nfilenames, opt)) return prc;
     std::vector<Task> mine;
     std::vector<uint32_t> ids;
     for (size_t i = 0; i < P.tasks.size(); i++)
@@ -1234,7 +1284,7 @@ int CSAMI_AddShardAssemble(const char *arcname, const char *const *filenames, in
     if (st) memset(st, 0, sizeof(*st));
     if (CSCMI_DeviceCheck() != 0) return CSCMI_DEVICE_ERROR;              // the index stream is encoded on the GPU
     AddPlan P;
-    plan_add(P, filenames, nfilenames, opt);
+    if (int prc = plan_add(P, filenames, nfilenames, opt)) return prc;
     struct Part { const uint8_t *files, *sizes, *data; uint32_t nfiles, nblocks; uint64_t len; };
     std::vector<Part> parts(P.tasks.size(), Part{nullptr, nullptr, nullptr, 0, 0, 0});
     for (int b = 0; b < nblobs; b++) {
@@ -1319,6 +1369,32 @@ int CSA_List(const char *arcname, const char *const *filenames, int nfilenames, 
                    kv.second.frags.empty() ? nullptr : kv.second.frags.data());
     }
     return 0;
+}
+
+// the plan CSA_Add would execute, without executing it (host only): number of tasks and the largest fragment count of any file
+int CSAMI_PlanInfo(const char *const *filenames, int nfilenames, const CSAOptions *opt, uint32_t *n_tasks, uint32_t *max_frags)
+{
+    AddPlan P;
+    int rc = plan_add(P, filenames, nfilenames, opt);
+    std::map<const void *, uint32_t> nfr;
+    uint32_t mx = 0;
+    for (const Task &t : P.tasks)
+        for (const FilePiece &f : t.files) mx = std::max(mx, ++nfr[(const void *)&*f.it]);
+    if (n_tasks) *n_tasks = (uint32_t)P.tasks.size();
+    if (max_frags) *max_frags = mx;
+    return rc;
+}
+
+int64_t CSA_IndexRoundTrip(const uint8_t *buf, uint64_t size, uint8_t *out, uint64_t cap)
+{
+    Index index;
+    BlockIndex abindex;
+    if (!unpack_index(index, abindex, buf, size)) return -1;
+    for (const auto &kv : index) if (!name_is_safe(kv.first)) return CSA_UNSAFE_NAME;
+    for (const auto &kv : index) if (kv.second.frags.size() > kMaxFrags) return -1;
+    std::vector<uint8_t> raw = pack_index(index, abindex, "");
+    if (out && cap) memcpy(out, raw.data(), (size_t)std::min<uint64_t>(cap, raw.size()));
+    return (int64_t)raw.size();
 }
 
 int64_t CSA_ReadIndex(const char *arcname, uint8_t *buf, uint64_t cap)

@@ -308,12 +308,14 @@ int CSCDec_Decode(CSCDecHandle p, ISeqOutStream *os, ICompressProgress *progress
     return ret;
 }
 
-// development aid (section timers of a -DCSCMI_TIMERS build; zeros in the product build)
+#ifdef CSCMI_TIMERS
+// development aid (section timers): only in the -DCSCMI_TIMERS build, never in the product library
 void CSCMI_DebugDecTimers(CSCDecHandle p, uint64_t *out16)
 {
     DecInstance *x = (DecInstance *)p;
     (void)hipMemcpy(out16, (const uint8_t *)x->d_state + offsetof(DecState, dbg), 16 * sizeof(uint64_t), hipMemcpyDeviceToHost);
 }
+#endif
 
 // Not in the reference: CSCDec_Decode for n independent handles at once (the tasks of an archive).  Every round
 // is ONE launch of k_decode_run_multi -- workgroup b advances stream b until it needs a block or has completed a

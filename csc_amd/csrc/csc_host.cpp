@@ -732,7 +732,8 @@ void CSCMI_GetStats(CSCEncHandle p, CSCMIStats *out)
     *out = e->stats;
 }
 
-// development aid (tools/gpu_timers.py with the -DCSCMI_TIMERS build); zeros in the product build
+#ifdef CSCMI_TIMERS
+// development aids (tools/gpu_timers.py, tools/gpu_trace.py): only in the -DCSCMI_TIMERS build, never in the product library
 void CSCMI_DebugTimers(CSCEncHandle p, uint64_t *out16)
 {
     EncInstance *e = (EncInstance *)p;
@@ -752,5 +753,6 @@ void CSCMI_DebugTrace(CSCEncHandle p, uint64_t *out768)
     (void)hipMemcpy(&ks, &e->d_state->stats, sizeof(ks), hipMemcpyDeviceToHost);
     memcpy(out768, ks.trace, sizeof(ks.trace));
 }
+#endif   // CSCMI_TIMERS
 
 }  // extern "C"

@@ -86,6 +86,15 @@ typedef void (*CSAListFn)(void *ctx, const char *name, int64_t esize, int64_t ed
 
 void CSA_OptionsInit(CSAOptions *o);
 
+/* Not in the reference: a file that the chosen split_count / task_bytes would cut into more than 127 fragments is refused
+ * before anything is written (the index keeps the count in one signed byte, csa_indexpack.cpp:84,105 -- the reference CLI
+ * writes such an archive and cannot read it back). */
+#define CSA_MAX_FRAGMENTS 127
+#define CSA_TOO_MANY_FRAGMENTS (-94)
+/* Extract / Test: entries whose stored name is empty or has a `..` component are skipped with a message and make the call
+ * return CSA_UNSAFE_NAME (after everything else was processed); the reference would follow them out of to_dir. */
+#define CSA_UNSAFE_NAME (-93)
+
 /* `csarc a [opts] arcname filenames...`.  Returns 0; 1 if the archive exists and !overwrite
  * (csarc.cpp:474-483); CSCMI_DEVICE_ERROR / READ_ERROR / WRITE_ERROR style negatives when the
  * encoder or the file system fails (the reference ignores those). */
@@ -105,7 +114,7 @@ void CSAMI_FreeBlob(uint8_t *blob);
 int CSAMI_AddShardAssemble(const char *arcname, const char *const *filenames, int nfilenames, const CSAOptions *o,
                            const uint8_t *const *blobs, const uint64_t *blob_lens, int nblobs, CSAStats *st);
 
-/* `csarc x`: 0 ok, 1 bad header (csarc.cpp:602-603), -1 decode error (csarc.cpp:464-468).
+/* `csarc x`: 0 ok, 1 bad header (csarc.cpp:602-603), -1 decode error (csarc.cpp:464-468), CSA_UNSAFE_NAME (above).
  * A failed adler32 is reported on stderr like the reference does and counted in st->verify_failures;
  * it does not change the return value (csa_io.h:331-332). */
 int CSA_Extract(const char *arcname, const char *const *filenames, int nfilenames, const CSAOptions *o, CSAStats *st);
@@ -115,6 +124,17 @@ int CSA_Test(const char *arcname, const char *const *filenames, int nfilenames, 
 
 /* `csarc l`: 0 ok, -1 bad header (csarc.cpp:654-655). */
 int CSA_List(const char *arcname, const char *const *filenames, int nfilenames, CSAListFn fn, void *ctx);
+
+/* The plan CSA_Add would execute for these names and options, without executing it (host only, no GPU): number of task
+ * streams and the largest fragment count any file gets.  Returns what CSA_Add would return at that point (0 or
+ * CSA_TOO_MANY_FRAGMENTS). */
+int CSAMI_PlanInfo(const char *const *filenames, int nfilenames, const CSAOptions *o, uint32_t *n_tasks, uint32_t *max_frags);
+
+/* Index pack / unpack round trip on a raw index buffer, for tests and fuzzing (no GPU involved): parses `buf` with the
+ * bounds-checked reader and, if it parses, re-packs it.  Returns the re-packed size (<= cap bytes are copied to out, out
+ * may be NULL), -1 if the buffer does not parse (truncated, counts beyond the buffer, negative fragment count),
+ * CSA_UNSAFE_NAME if it parses but holds a name Extract would refuse. */
+int64_t CSA_IndexRoundTrip(const uint8_t *buf, uint64_t size, uint8_t *out, uint64_t cap);
 
 /* The raw (unpacked) index bytes of an archive, for tools and tests: returns the raw size, or -1.
  * Copies at most cap bytes into buf (buf may be NULL to query the size). */

@@ -340,16 +340,21 @@ def test_sharded_add_two_processes(csa, case, tmp_path):
 
 
 def test_bench_multi_rank_path_two_processes(tmp_path):
-    """bench.py's N > 1 branch (task r on rank r, barrier + max-over-ranks timing, hand-over of the streams to rank 0) with
-    two ranks sharing the one GPU of this box over gloo (CSC_BENCH_BACKEND, tests only; the driver's runs use RCCL)"""
-    env = dict(os.environ, CSC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29583", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                         cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    """`python bench.py --gpus 2` exactly as the driver types it: the script starts its own two ranks (child torchrun), which run
+    the -p8 tasks of the 10^9-byte stand-in (4 per rank, one batch launch per step), barrier + max-over-ranks timing, per-task
+    digests against the reference's (tests/golden/split_prefix_digests.json) and the hand-over of the streams to rank 0.
+    Two ranks share the one GPU of this box over gloo (CSC_BENCH_BACKEND, tests only; the driver's runs use RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(CSC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                         cwd=tmp_path, env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1, out.stdout[-2000:]
     d = json.loads(line[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["cpu_baseline"] is None
+    assert d["tasks_per_rank"] == [4, 4] and len(d["tasks"]) == 8
+    assert d["bit_exact_vs_reference"] is True, d["tasks"]
+    assert {t["rank"] for t in d["tasks"]} == {0, 1} and all(t["chunks"] == 2 for t in d["tasks"])
     assert d["exchange"]["ok"] is True and d["exchange"]["bytes"] > 0
-    assert 0 < d["value"] < 100 and d["roofline"]["launches"] == 1
+    assert 0 < d["value"] < 1000 and d["roofline"]["launches"] == 1 and d["roofline"]["frac"] > 0

@@ -10,7 +10,7 @@ from csc_amd.capi import CscLib, BytesReader, BytesWriter, CSC_PROP_SIZE
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 mib = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 kind = sys.argv[3] if len(sys.argv) > 3 else "text"
-lib = CscLib(os.path.join(ROOT, "csc_amd", "libcsc_mi355x_dectimers.so"))
+lib = CscLib(os.path.join(ROOT, "csc_amd", "csrc", "build", "dev", "libcsc_mi355x_timers.so"))
 orc = CscLib(os.path.join(ROOT, "oracle", "liborc.so")); orc.lib.orc_zero_alloc.restype = C.c_void_p
 data = corpus.fill(kind, corpus.SEED_ENWIK9, 0, mib << 20).tobytes()
 rc, s = orc.encode(data, level, 16 << 20, alloc=orc.lib.orc_zero_alloc())

@@ -9,7 +9,7 @@ from csc_amd import corpus
 from csc_amd.capi import CscLib, BytesWriter
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 mib = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-lib = CscLib(sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "csc_amd", "libcsc_mi355x_timers.so"))
+lib = CscLib(sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "csc_amd", "csrc", "build", "dev", "libcsc_mi355x_timers.so"))
 PAIR = len(sys.argv) > 3
 class St(C.Structure):
     _fields_ = [("chunks", C.c_uint64), ("input_bytes", C.c_uint64), ("output_bytes", C.c_uint64), ("encode_launches", C.c_uint64),
