@@ -314,7 +314,8 @@ std::vector<Task> cap_tasks(const std::vector<Task> &in, uint64_t cap)
         Task cur;
         for (const FilePiece &f : t.files) {
             const uint64_t ns = slices[(const void *)&*f.it], whole = (uint64_t)f.it->second.esize;
-            const uint64_t min_piece = ns < 127 ? (whole + (127 - ns) - 1) / (127 - ns) : whole;
+            const uint64_t room127 = ns <= 1 ? 127 : (ns < 127 ? 127 - ns : 0);              // an unsplit file has no slice tails
+            const uint64_t min_piece = room127 ? (whole + room127 - 1) / room127 : whole;
             uint64_t off = f.off, left = f.size;
             if (left == 0) { cur.add(f.path, off, 0, 0, 0, f.it); continue; }
             while (left) {

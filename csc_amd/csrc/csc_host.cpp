@@ -507,6 +507,8 @@ CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *outstream, ISzA
         bool bt = props->bt_hash_bits && props->bt_size;
         bool ht = props->hash_bits && props->hash_width;
         if (!bt && ht && props->hash_width <= 9) e->parser |= 4;
+        // level-3 geometry: the pipeline form of the advanced parser (csc_kernels_dp4.inc)
+        if ((e->parser & 4) && props->lz_mode == 3 && props->hash_width <= 2 && props->good_len >= 2 && props->good_len <= 32) e->parser |= 8;
     }
     bool ok = hipGetDevice(&e->device) == hipSuccess;
     // each process/thread may sit on another device: the constant tables are per device
@@ -646,7 +648,7 @@ int CSCMI_EncodeDeviceChunkBatch(int n, CSCEncHandle *hs, const void *const *dev
     for (int i = 0; i < n && !rc; i++) rc = sizes[i] ? chunk_segment((EncInstance *)hs[i], sizes[i], true) : 0;
     if (rc) return rc;
     // one launch per parser flavour over every handle that still has runs pending
-    for (int parser = 2; parser <= 7; parser++) {
+    for (int parser = 2; parser <= 15; parser++) {
         if ((parser & 3) < 2) continue;
         uint32_t m = 0;
         EncState **st = (EncState **)h_batch;

@@ -131,6 +131,7 @@ struct EncLds {
 struct Sc {
     EncState *S;
     EncLds *L;
+    void *X;                         // Dp4X (csc_kernels_dp4.inc) when the kernel has one
     gu8 *wnd;
     uint32_t wnd_size, vld_rge;
     gu32 *ht2, *ht3, *ht6, *bt_head, *bt_nodes, *p_lit, *p_delta, *mfbuf;
@@ -639,6 +640,14 @@ DEV void compress_rle(Sc &c, const gu8 *src, uint32_t size)
 #include "csc_kernels_lz.inc"
 #include "csc_kernels_dp2.inc"
 #include "csc_kernels_dp3.inc"
+#if CSCMI_TU != 2
+#include "csc_kernels_dp4.inc"
+#else
+DEV void lz_compress_advanced_dp4(Sc &, uint32_t) {}
+DEV void d4_init(Sc &) {}
+DEV void d4_worker(Sc &) {}
+DEV void d4_quit(Sc &) {}
+#endif
 #include "csc_kernels_blocks.inc"
 
 }  // namespace cscmi

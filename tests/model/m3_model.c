@@ -1,0 +1,484 @@
+/*
+ * tests/model/m3_model.c -- CPU model of the ARRANGEMENT the HIP kernels give LZ::compress_advanced on the hash-table
+ * levels (csc_amd/csrc/csc_kernels_dp4.inc).  TEST INFRASTRUCTURE: it includes the oracle's encoder, replaces only
+ * compress_advanced (csc_lz.cpp:207-333) through the oracle's test hook, and must produce the oracle's bytes
+ * (tests/test_m3_model.py).  What it proves, before any of it runs on a GPU:
+ *
+ *  1. SPECULATIVE MATCH-FINDER PRE-PASS.  Every position of a sub-block is inserted ahead of the parser with find_match's
+ *     rule (HT2/HT3 overwrite, bucket shift; csc_mf.cpp:365-366,487-491), 64 positions per batch: all table words are
+ *     gathered first, same-key positions inside the batch are resolved in registers, one store per touched word.  The
+ *     parser's SlidePos (csc_mf.cpp:134-206) inserts the same words EXCEPT (a) the long-match skip (:145) and (b) the
+ *     same-hash no-shift rule (:150-156); a slid range that contains neither needs nothing, one that does is undone
+ *     (the gathered words are the undo log) and replayed exactly.
+ *  2. PARSE-INDEPENDENT HASH CANDIDATES.  Distance, full match length, bound[] verdict and the distance-gating of
+ *     HT2 -> HT3 -> bucket depend on the tables and the window only; find_match's sequential acceptance (:266-485) is
+ *     then a prefix maximum over the 4 rep slots + the hash slots.
+ *  3. REP MATCH LENGTHS FROM EQUALITY MASKS.  For a distance d, bit t of mask(base) says wnd[base+t] == wnd[base+t-d];
+ *     the match length of a rep candidate at any node is a count of trailing ones, capped like the reference caps it
+ *     (limit, window end).  A pushed hash candidate brings its mask along, so the rep lengths after a match need no load.
+ *  4. THE DP IN A RING RELATIVE TO THE CURRENT NODE (lane l = node k + l), labels carrying coder state and four entry
+ *     ids instead of being derived at visit time (:231-268), relaxation in node order with the reference's strict `<`.
+ */
+#include <stdio.h>
+#include "../../oracle/orc_encoder.c"
+
+#define M3_NS 12          /* hash slots: 0 HT2, 1 HT3, 2.. bucket */
+#define M3_RING 32
+#define M3_INF 0xFFFFFFFFu
+
+typedef struct {
+    uint32_t dist, ent;   /* candidate distance (pos - ent); ent = table word before this position's insert */
+    uint32_t ml;          /* full common-prefix length under the reference's caps */
+    int eid;              /* entry id (mask) when pushable, else -1 */
+    uint8_t cons, drop;
+    uint32_t dcost;       /* (slot > 2 ? slot + 2 : 2) * 128 of GetMatchDistPrice */
+} M3Slot;
+typedef struct {
+    M3Slot s[M3_NS];
+    uint32_t h2, h3, h6;
+    uint8_t hdev;         /* h6 == h6 of the previous position, or h6 == 0: SlidePos would not shift here */
+} M3Rec;
+typedef struct { uint32_t dist, base, cov_end; uint64_t mask; int fwd; uint32_t req_at; } M3Ent;
+
+static struct {
+    M3Rec *rec;           /* one per position of the sub-block */
+    M3Ent *ent; int nent, cap_ent;
+    int rid[4];           /* entry ids of LZ::rep_dist_ */
+    uint32_t sb0, pos0, size, ih, ch;
+    int la, refresh_delay, refresh_at;
+    /* statistics */
+    unsigned long long n_nodes, n_windows, n_slide, n_dev, n_undo_pos, n_slow, n_refresh, n_batches, n_exact_pos, n_direct_lit;
+    unsigned long long n_len_gt129, n_hdev_events;
+} M;
+
+static void m3_die(const char *what) { fprintf(stderr, "m3_model: %s\n", what); abort(); }
+
+static int m3_new_ent(uint32_t dist, uint32_t base, uint64_t mask, uint32_t cov_end)
+{
+    if (M.nent == M.cap_ent) { M.cap_ent = M.cap_ent ? M.cap_ent * 2 : 4096; M.ent = (M3Ent *)realloc(M.ent, sizeof(M3Ent) * (size_t)M.cap_ent); }
+    M3Ent *x = &M.ent[M.nent];
+    x->dist = dist; x->base = base; x->mask = mask; x->cov_end = cov_end; x->fwd = -1; x->req_at = 0xFFFFFFFFu;
+    return M.nent++;
+}
+
+/* bit t: wnd[base + t] == wnd[(base + t - d) mod wnd_size], for base + t < sb_end (later bits are never used) */
+static uint64_t m3_eq_mask(const OrcEnc *e, uint32_t base, uint32_t d, uint32_t sb_end)
+{
+    uint64_t m = 0;
+    for (uint32_t t = 0; t < 64 && base + t < sb_end; t++) {
+        uint32_t q = base + t, src = q >= d ? q - d : q + e->wnd_size - d;
+        if (e->wnd[q] == e->wnd[src]) m |= 1ull << t;
+    }
+    return m;
+}
+
+/* match length of distance-entry x at window position wpos under find_match's caps (:267-279); *slow = the mask did not cover it */
+static uint32_t m3_rep_len(OrcEnc *e, const M3Ent *x, uint32_t wpos, uint32_t limit, int *slow)
+{
+    uint32_t d = x->dist;
+    uint32_t cmp_pos = wrap_back(e, wpos, d);
+    uint32_t climit = UMIN(limit, e->wnd_size - cmp_pos);
+    uint32_t direct = prefix_len(e->wnd + wpos, e->wnd + cmp_pos, climit);
+    uint32_t off = wpos - x->base;
+    *slow = 0;
+    if (wpos < x->base || off >= 64) { *slow = 1; return direct; }
+    uint64_t v = ~(x->mask >> off);
+    uint32_t run = v ? (uint32_t)__builtin_ctzll(v) : 64;
+    if (run > 64 - off) run = 64 - off;
+    uint32_t ml = UMIN(run, climit);
+    if (off + run >= 64 && run < climit) { *slow = 1; return direct; }     /* ran off the end of the mask: extend by loads */
+    if (ml != direct) { fprintf(stderr, "mask %u direct %u off %u d %u wpos %u base %u climit %u\n", ml, direct, off, d, wpos, x->base, climit); m3_die("eq-mask length differs from the direct compare"); }
+    return ml;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+/* inserter: positions [i0, i0 + n) of the sub-block, n <= 64, find_match's insert rule, batch form                  */
+static void m3_insert_batch(OrcEnc *e, uint32_t i0, uint32_t n)
+{
+    const uint32_t W = UMIN(e->ht_width, e->ht_cyc);
+    uint32_t o2[64], o3[64], ob[64][M3_NS];
+    M.n_batches++;
+    for (uint32_t l = 0; l < n; l++) {            /* hashes + ONE gather per lane, before any store */
+        M3Rec *r = &M.rec[i0 + l];
+        const uint8_t *p = e->wnd + M.sb0 + i0 + l;
+        r->h2 = hash2(p); r->h3 = hash3(p); r->h6 = hash6(p, e->ht_bits);
+        o2[l] = e->ht2[r->h2]; o3[l] = e->ht3[r->h3];
+        for (uint32_t w = 0; w < W; w++) ob[l][w] = e->ht6[(size_t)r->h6 * e->ht_width + w];
+    }
+    for (uint32_t l = 0; l < n; l++) {            /* same-key lanes inside the batch, resolved "in registers" */
+        M3Rec *r = &M.rec[i0 + l];
+        const uint32_t pos = M.pos0 + i0 + l;
+        uint32_t e2 = o2[l], e3 = o3[l], eb[M3_NS + 64];
+        uint32_t nb = 0;
+        for (int j = (int)l - 1; j >= 0; j--) if (M.rec[i0 + j].h2 == r->h2) { e2 = M.pos0 + i0 + (uint32_t)j; break; }
+        for (int j = (int)l - 1; j >= 0; j--) if (M.rec[i0 + j].h3 == r->h3) { e3 = M.pos0 + i0 + (uint32_t)j; break; }
+        for (int j = (int)l - 1; j >= 0 && nb < W; j--) if (M.rec[i0 + j].h6 == r->h6) eb[nb++] = M.pos0 + i0 + (uint32_t)j;
+        for (uint32_t w = 0; w < W && nb < W; w++) eb[nb++] = ob[l][w];
+        r->s[0].ent = e2; r->s[0].dist = pos - e2;
+        r->s[1].ent = e3; r->s[1].dist = pos - e3;
+        for (uint32_t w = 0; w < W; w++) { r->s[2 + w].ent = eb[w]; r->s[2 + w].dist = pos - eb[w]; }
+        {
+            const uint32_t prev_h6 = (i0 + l) ? M.rec[i0 + l - 1].h6 : 0xFFFFFFFFu;
+            r->hdev = (r->h6 == 0 || r->h6 == prev_h6) ? 1 : 0;
+        }
+    }
+    for (uint32_t l = 0; l < n; l++) {            /* one store per touched word: the LAST lane of a key writes */
+        M3Rec *r = &M.rec[i0 + l];
+        const uint32_t pos = M.pos0 + i0 + l;
+        int last2 = 1, last3 = 1, last6 = 1;
+        for (uint32_t j = l + 1; j < n; j++) {
+            if (M.rec[i0 + j].h2 == r->h2) last2 = 0;
+            if (M.rec[i0 + j].h3 == r->h3) last3 = 0;
+            if (M.rec[i0 + j].h6 == r->h6) last6 = 0;
+        }
+        if (last2) e->ht2[r->h2] = pos;
+        if (last3) e->ht3[r->h3] = pos;
+        if (last6 && W) {
+            uint32_t *b = e->ht6 + (size_t)r->h6 * e->ht_width;
+            for (uint32_t w = W - 1; w > 0; w--) b[w] = r->s[2 + w - 1].ent;
+            b[0] = pos;
+        }
+    }
+}
+
+/* compare stage for position i: which hash slots find_match would look at, their full lengths, bound[] verdicts, masks */
+static void m3_compare(OrcEnc *e, uint32_t i)
+{
+    M3Rec *r = &M.rec[i];
+    const uint32_t W = UMIN(e->ht_width, e->ht_cyc);
+    const uint32_t wpos = M.sb0 + i, limit = M.size - i, vld = e->vld_rge, sb_end = M.sb0 + M.size;
+    uint32_t Mx = 0;                                   /* running distance of the HT chain (:301-363, :453-485), no good_len hit */
+    for (uint32_t s = 0; s < 2 + W; s++) {
+        M3Slot *q = &r->s[s];
+        q->cons = 0; q->drop = 0; q->ml = 0; q->eid = -1; q->dcost = 0;
+        if (q->dist <= Mx) continue;
+        Mx = q->dist;
+        if (q->dist >= vld) continue;
+        q->cons = 1;
+        uint32_t cmp_pos;
+        if (s == 0) cmp_pos = wpos > q->dist ? wpos - q->dist : wpos + e->wnd_size - q->dist;     /* HT2: strict, :306 */
+        else cmp_pos = wrap_back(e, wpos, q->dist);
+        uint32_t climit = UMIN(limit, e->wnd_size - cmp_pos);
+        q->ml = prefix_len(e->wnd + wpos, e->wnd + cmp_pos, climit);
+        q->drop = (q->ml <= 6 && q->dist >= kBound[q->ml]) ? 1 : 0;
+        if (q->ml >= 2 && !q->drop) {
+            q->eid = m3_new_ent(q->dist, wpos, m3_eq_mask(e, wpos, q->dist, sb_end), sb_end);
+            uint32_t l = dist_slot(q->dist - 1);
+            q->dcost = (l > 2 ? l + 2 : 2) * 128;
+        }
+    }
+}
+
+static void m3_ensure(OrcEnc *e, uint32_t i_master)
+{
+    uint32_t target = UMIN(M.size, i_master + (uint32_t)M.la);
+    if (target <= i_master) target = UMIN(M.size, i_master + 1);
+    while (M.ih < target) {
+        uint32_t n = UMIN(64u, M.size - M.ih);
+        m3_insert_batch(e, M.ih, n);
+        M.ih += n;
+    }
+    while (M.ch < M.ih) { m3_compare(e, M.ch); M.ch++; }
+}
+
+/* SlidePos (csc_mf.cpp:134-206, hash tables only) for sub-block positions [from, s + len), the match starting at s */
+static void m3_exact_slide(OrcEnc *e, uint32_t s, uint32_t len, uint32_t from, uint32_t lasth6)
+{
+    const uint32_t W = UMIN(e->ht_width, e->ht_cyc);
+    for (uint32_t i = from - s; i < len;) {
+        const uint8_t *p = e->wnd + M.sb0 + s + i;
+        const uint32_t pos = M.pos0 + s + i;
+        e->ht2[hash2(p)] = pos;
+        e->ht3[hash3(p)] = pos;
+        if (i + 128 < len) { i += 4; continue; }
+        if (e->ht_width) {
+            uint32_t h6 = hash6(p, e->ht_bits);
+            uint32_t *b = e->ht6 + (size_t)h6 * e->ht_width;
+            if (h6 != lasth6) for (uint32_t j = W - 1; j > 0; j--) b[j] = b[j - 1];
+            b[0] = pos;
+            lasth6 = h6;
+        }
+        i++;
+        M.n_exact_pos++;
+    }
+}
+
+/* take back the speculative inserts of positions [a, ih): 64 at a time from the top, the FIRST position of a key in a batch
+ * restores the word (its gathered value is the oldest) */
+static void m3_undo(OrcEnc *e, uint32_t a)
+{
+    const uint32_t W = UMIN(e->ht_width, e->ht_cyc);
+    uint32_t hi = M.ih;
+    while (hi > a) {
+        uint32_t lo = hi - a > 64 ? hi - 64 : a;
+        for (uint32_t q = lo; q < hi; q++) {
+            M3Rec *r = &M.rec[q];
+            int f2 = 1, f3 = 1, f6 = 1;
+            for (uint32_t j = lo; j < q; j++) {
+                if (M.rec[j].h2 == r->h2) f2 = 0;
+                if (M.rec[j].h3 == r->h3) f3 = 0;
+                if (M.rec[j].h6 == r->h6) f6 = 0;
+            }
+            if (f2) e->ht2[r->h2] = r->s[0].ent;
+            if (f3) e->ht3[r->h3] = r->s[1].ent;
+            if (f6) for (uint32_t w = 0; w < W; w++) e->ht6[(size_t)r->h6 * e->ht_width + w] = r->s[2 + w].ent;
+            M.n_undo_pos++;
+        }
+        hi = lo;
+    }
+}
+
+/* the parser slid over [s + 1, s + len) instead of searching there */
+static void m3_slide_event(OrcEnc *e, uint32_t s, uint32_t len)
+{
+    if (len <= 1) return;
+    const uint32_t a = s + 1, b = s + len;
+    M.n_slide++;
+    if (len > 129) M.n_len_gt129++;
+    if (M.ih <= a) {                                   /* nothing speculated there yet */
+        m3_exact_slide(e, s, len, a, 0);
+        M.ih = b; M.ch = b;
+        return;
+    }
+    const uint32_t hi = UMIN(M.ih, b);
+    int dev = len > 129;
+    for (uint32_t q = a; q < hi && !dev; q++) if (M.rec[q].hdev) { dev = 1; M.n_hdev_events++; }
+    if (!dev) {
+        if (hi < b) {                                  /* the rest of the range: SlidePos itself, continuing its lasth6 */
+            m3_exact_slide(e, s, len, hi, M.rec[hi - 1].h6);
+            M.ih = b; M.ch = b;
+        }
+        return;                                        /* the speculative inserts ARE SlidePos's */
+    }
+    M.n_dev++;
+    m3_undo(e, a);
+    m3_exact_slide(e, s, len, a, 0);
+    M.ih = b; M.ch = b;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+/* the parser                                                                                                        */
+typedef struct { uint32_t price, dist, back, state; int id[4]; } M3Lab;
+
+static void m3_perm_ids(int *out, const int *in, uint32_t code, int newid)
+{
+    /* encode_nonlit's rep bookkeeping (csc_lz.cpp:127-154) on ids: code 1..4 = rep index + 1, else a new distance */
+    if (code <= 4) {
+        uint32_t k = code - 1;
+        out[0] = in[k];
+        for (uint32_t j = 1, t = 0; j < 4; t++) { if (t == k) continue; out[j++] = in[t]; }
+    } else { out[0] = newid; out[1] = in[0]; out[2] = in[1]; out[3] = in[2]; }
+}
+
+static void m3_adv(OrcEnc *e, uint32_t size)
+{
+    const uint32_t W = UMIN(e->ht_width, e->ht_cyc);
+    if (e->bt_head || !e->ht_width || W > M3_NS - 2 || e->lz_good_len > M3_RING || e->lz_good_len < 2 || size == 0
+        || e->pos >= 0xFFFF0000u) { lz_compress_advanced(e, size); return; }
+    const uint32_t NS = 2 + W, vld = e->vld_rge;
+    M.sb0 = e->wnd_curpos; M.pos0 = e->pos; M.size = size; M.ih = 0; M.ch = 0;
+    const uint32_t sb_end = M.sb0 + size;
+    M.rec = (M3Rec *)calloc(size, sizeof(M3Rec));
+    M.nent = 0;
+    /* the stream's rep distances get fresh masks at every sub-block start */
+    for (int r = 0; r < 4; r++) M.rid[r] = m3_new_ent(e->rep_dist[r], M.sb0, e->rep_dist[r] < vld ? m3_eq_mask(e, M.sb0, e->rep_dist[r], sb_end) : 0, sb_end);
+    static uint32_t fin_dist[AP_LIMIT + 2], fin_back[AP_LIMIT + 2];
+
+    for (uint32_t i = 0; i < size;) {
+        const uint32_t w0 = i, aplimit = UMIN((uint32_t)AP_LIMIT, size - i);
+        /* per coder state, fixed while the window is open (nothing is coded inside it) */
+        uint32_t lit_flag[64], p1flag[64], match_base[64], rep_price[64][4];
+        for (uint32_t s = 0; s < 64; s++) {
+            lit_flag[s] = bit_price(e, 0, e->p_state[s * 3]);
+            p1flag[s] = rep0len1_price(e, s);
+            match_base[s] = bit_price(e, 1, e->p_state[s * 3]) + bit_price(e, 1, e->p_state[s * 3 + 1]);
+            for (uint32_t r = 0; r < 4; r++) rep_price[s][r] = rep_dist_price(e, s, r);
+        }
+        M3Lab ring[M3_RING + 1];
+        for (int l = 0; l <= M3_RING; l++) ring[l].price = M3_INF;
+        ring[0].price = 0; ring[0].dist = 0; ring[0].back = 0; ring[0].state = e->state;
+        memcpy(ring[0].id, M.rid, sizeof(M.rid));
+        uint32_t reach = 0, k = 0, a0l = 1, a0code = 0, exit_kind = 0;
+        int a0id = -1;
+        M3Lab cur;
+        M.n_windows++;
+        for (;; k++) {
+            const uint32_t p = w0 + k, wpos = M.sb0 + p, limit = size - p;
+            cur = ring[0];
+            fin_dist[k] = cur.dist; fin_back[k] = cur.back;
+            M.n_nodes++;
+            if (k == aplimit) { exit_kind = 1; break; }                       /* :271 */
+            m3_ensure(e, p);
+            const M3Rec *r = &M.rec[p];
+            /* ---- candidates: 4 rep slots from masks, hash slots from the record ---- */
+            uint32_t L[4 + M3_NS], code[4 + M3_NS], dprice[4 + M3_NS], cdist[4 + M3_NS];
+            int cid[4 + M3_NS];
+            uint8_t cons[4 + M3_NS], drop[4 + M3_NS];
+            for (uint32_t s = 0; s < 4; s++) {
+                /* a refreshed mask that has arrived replaces the id in the label (and so in everything relaxed from it) */
+                if (M.ent[cur.id[s]].fwd >= 0 && p >= M.ent[cur.id[s]].req_at + (uint32_t)M.refresh_delay) cur.id[s] = M.ent[cur.id[s]].fwd;
+                M3Ent *x = &M.ent[cur.id[s]];
+                cons[s] = x->dist < vld; drop[s] = 0; L[s] = 0; code[s] = 1 + s; cid[s] = cur.id[s]; cdist[s] = 0;
+                dprice[s] = rep_price[cur.state][s];
+                if (cons[s]) {
+                    int slow;
+                    L[s] = m3_rep_len(e, x, wpos, limit, &slow);
+                    if (slow) M.n_slow++;
+                    if (wpos - x->base > (uint32_t)M.refresh_at && x->fwd < 0 && x->cov_end > wpos) {   /* ask for a mask based here */
+                        x->fwd = m3_new_ent(x->dist, wpos, m3_eq_mask(e, wpos, x->dist, sb_end), sb_end);
+                        x = &M.ent[cur.id[s]];     /* (the table may have moved) */
+                        x->req_at = p;
+                        M.n_refresh++;
+                    }
+                }
+            }
+            for (uint32_t s = 0; s < NS; s++) {
+                const M3Slot *q = &r->s[s];
+                cons[4 + s] = q->cons; drop[4 + s] = q->drop; L[4 + s] = q->cons ? q->ml : 0;
+                code[4 + s] = 4 + q->dist; cid[4 + s] = q->eid; cdist[4 + s] = q->dist;
+                dprice[4 + s] = match_base[cur.state] + q->dcost;
+            }
+            /* ---- find_match's acceptance as a prefix maximum (:266-485) ---- */
+            uint32_t pm = 0, premax = 1, has1 = (cons[0] && L[0] >= 2) ? 1u : 0u, n = 0;
+            for (uint32_t s = 0; s < 4 + NS; s++) {
+                const uint32_t Ls = cons[s] ? L[s] : 0;
+                if (cons[s] && Ls > premax && !drop[s]) pm |= 1u << s;
+                if (Ls > premax) premax = Ls;
+                if ((pm >> s) & 1u) if (Ls >= e->good_len) break;            /* everything after the first good_len hit is ignored */
+            }
+            n = (uint32_t)__builtin_popcount(pm) + has1;
+            a0l = 1; a0code = 0; a0id = -1;
+            if (pm) { uint32_t top = 31u - (uint32_t)__builtin_clz(pm); a0l = L[top]; a0code = code[top]; a0id = cid[top]; }
+            else if (has1) { a0l = 1; a0code = 1; }
+            if (k == 0 && n == 0) { exit_kind = 4; break; }                    /* :213: no candidate at all -> plain literal */
+            /* ---- FindMatchWithPrice's table (:600-624): length l in "lane" l ---- */
+            uint32_t lane_code[M3_RING + 1] = {0}, lane_price[M3_RING + 1] = {0};
+            int lane_id[M3_RING + 1];
+            if (a0l < e->good_len) {
+                uint32_t prevL = 1, nt = 0;
+                uint32_t own[M3_RING + 1];
+                for (uint32_t s = 0; s < 4 + NS; s++) {
+                    if (!((pm >> s) & 1u)) continue;
+                    for (uint32_t l = prevL + 1; l <= L[s]; l++) {
+                        own[l] = s;
+                        const uint32_t rdist = s < 4 ? 0 : cdist[s];
+                        lane_code[l] = (l <= 6 && rdist >= kBound[l]) ? 0 : code[s];
+                        lane_id[l] = cid[s];
+                        if (lane_code[l]) nt++;                                  /* GetMatchLenPrice ticks (l - 2 < 32 always here) */
+                    }
+                    prevL = L[s];
+                }
+                /* the 4097-call refresh of the length prices (csc_model.cpp:286-299), calls numbered in length order */
+                uint32_t old_lp[32], trigger = 0xFFFFFFFFu;
+                if (nt && e->lp_rebuild_int < nt) {
+                    memcpy(old_lp, e->len_price, sizeof(old_lp));
+                    trigger = e->lp_rebuild_int;
+                    len_price_rebuild(e);
+                    e->lp_rebuild_int = 4096 - (nt - trigger - 1);
+                } else e->lp_rebuild_int -= nt;
+                uint32_t idx = 0;
+                for (uint32_t l = 2; l <= a0l; l++) {
+                    if (!lane_code[l]) continue;
+                    const uint32_t lp = (trigger != 0xFFFFFFFFu && idx < trigger) ? old_lp[l - 2] : e->len_price[l - 2];
+                    lane_price[l] = dprice[own[l]] + lp;
+                    idx++;
+                }
+            }
+            /* ---- ways out (:277, :290) ---- */
+            if (a0l == 1 && reach == k) { exit_kind = 2; break; }
+            if (a0l >= e->lz_good_len || (a0l > 1 && a0l + k >= aplimit)) { exit_kind = 3; break; }
+            if (k + a0l > reach) reach = k + a0l;
+            /* ---- relaxation: lane 1 literal then rep0len1 (:301-313), lanes 2.. the match lengths (:315-326) ---- */
+            {
+                const uint32_t lit_ctx = wpos ? e->wnd[wpos - 1] : 0;
+                const uint32_t tree = literal_price(e, cur.state, lit_ctx, e->wnd[wpos]) - lit_flag[cur.state];
+                uint32_t c1 = tree + lit_flag[cur.state] + cur.price, k1 = 0;
+                if (has1 && p1flag[cur.state] + cur.price < c1) { c1 = p1flag[cur.state] + cur.price; k1 = 1; }
+                if (c1 < ring[1].price) {
+                    ring[1].price = c1; ring[1].dist = k1; ring[1].back = k;
+                    ring[1].state = (cur.state * 4 + (k1 ? 2u : 0u)) & 0x3F;
+                    memcpy(ring[1].id, cur.id, sizeof(cur.id));
+                }
+            }
+            for (uint32_t l = 2; l <= a0l; l++) {
+                if (!lane_code[l]) continue;
+                const uint32_t np = lane_price[l] + cur.price;
+                if (np < ring[l].price) {
+                    ring[l].price = np; ring[l].dist = lane_code[l]; ring[l].back = k;
+                    ring[l].state = (cur.state * 4 + (lane_code[l] <= 4 ? 3u : 1u)) & 0x3F;
+                    m3_perm_ids(ring[l].id, cur.id, lane_code[l], lane_id[l]);
+                }
+            }
+            /* ---- the ring moves on by one node ---- */
+            memmove(&ring[0], &ring[1], sizeof(M3Lab) * M3_RING);
+            ring[M3_RING].price = M3_INF;
+        }
+        /* ---- way out: back-trace over the log (csc_lz.cpp:335-362), then what the exit itself codes ---- */
+        const uint32_t end = k;
+        if (exit_kind == 4) {
+            encode_literal(e, e->wnd[M.sb0 + w0]);
+            M.n_direct_lit++;
+            i++;
+            continue;
+        }
+        {
+            static uint32_t nxt[AP_LIMIT + 2];
+            for (uint32_t t = end; t;) { nxt[fin_back[t]] = t; t = fin_back[t]; }
+            for (uint32_t t = 0; t != end;) {
+                const uint32_t next = nxt[t], nd = fin_dist[next];
+                if (nd == 0) encode_literal(e, e->wnd[M.sb0 + w0 + t]);
+                else if (nd <= 4) {
+                    if (next - t == 1 && nd == 1) encode_rep0len1(e);
+                    else encode_rep_match(e, nd - 1, next - t - 2);
+                    e->ctx = e->wnd[M.sb0 + w0 + next - 1];
+                } else {
+                    encode_match(e, nd - 5, next - t - 2);
+                    e->ctx = e->wnd[M.sb0 + w0 + next - 1];
+                }
+                t = next;
+            }
+            /* rep_dist_ = ap[end].rep_dist (:358-361): the ids of the exit node's label, distances from their entries */
+            memcpy(M.rid, cur.id, sizeof(cur.id));
+            for (int r = 0; r < 4; r++) e->rep_dist[r] = M.ent[M.rid[r]].dist;
+        }
+        i += end;
+        if (exit_kind == 2) {
+            encode_literal(e, e->wnd[M.sb0 + i]);
+            i++;
+        } else if (exit_kind == 3) {
+            MFUnit u; u.len = a0l; u.dist = a0code;
+            int nid[4];
+            if (!(a0l == 1 && a0code == 1)) { m3_perm_ids(nid, M.rid, a0code, a0id); memcpy(M.rid, nid, sizeof(nid)); }
+            lz_encode_nonlit(e, u);
+            for (int r = 0; r < 4; r++) if (e->rep_dist[r] != M.ent[M.rid[r]].dist) m3_die("rep ids and rep distances disagree");
+            m3_slide_event(e, i, a0l);
+            i += a0l;
+            e->ctx = e->wnd[M.sb0 + i - 1];
+        }
+    }
+    /* whatever the parser never reached was inserted speculatively beyond the sub-block?  No: the pre-pass stops at `size` */
+    if (M.ih < size) m3_ensure(e, size - 1);
+    if (M.ih != size) m3_die("inserter did not end at the sub-block end");
+    e->pos = M.pos0 + size;
+    e->wnd_curpos = M.sb0 + size;
+    free(M.rec); M.rec = NULL;
+}
+
+static void m3_stats_atexit(void)
+{
+    if (!getenv("M3_STATS")) return;
+    fprintf(stderr, "m3_model: nodes %llu windows %llu direct-literals %llu | slide events %llu (len>129: %llu, same-hash: %llu) deviations %llu undone positions %llu exact positions %llu | "
+            "batches %llu | mask refreshes %llu slow-path rep compares %llu\n",
+            M.n_nodes, M.n_windows, M.n_direct_lit, M.n_slide, M.n_len_gt129, M.n_hdev_events, M.n_dev, M.n_undo_pos, M.n_exact_pos, M.n_batches, M.n_refresh, M.n_slow);
+}
+
+__attribute__((constructor)) static void m3_install(void)
+{
+    const char *s;
+    M.la = (s = getenv("M3_LA")) ? atoi(s) : 192;
+    M.refresh_delay = (s = getenv("M3_REFRESH_DELAY")) ? atoi(s) : 6;
+    M.refresh_at = (s = getenv("M3_REFRESH_AT")) ? atoi(s) : 16;
+    if (M.la < 1) M.la = 1;
+    orc_adv_hook = m3_adv;
+    atexit(m3_stats_atexit);
+}

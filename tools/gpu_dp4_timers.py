@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Development aid: section timers of the pipeline form's master wavefront (the -DCSCMI_TIMERS build).
+make -C csc_amd/csrc dev;  gpurun -- python tools/gpu_dp4_timers.py [MiB]"""
+import ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa
+from csc_amd import corpus
+from csc_amd.capi import CscLib, BytesWriter
+mib = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+lib = CscLib(os.path.join(ROOT, "csc_amd", "csrc", "build", "dev", "libcsc_mi355x_timers.so"))
+class St(C.Structure):
+    _fields_ = [("chunks", C.c_uint64), ("input_bytes", C.c_uint64), ("output_bytes", C.c_uint64), ("encode_launches", C.c_uint64),
+                ("encode_kernel_ms", C.c_double), ("analyze_kernel_ms", C.c_double), ("find", C.c_uint64), ("slide", C.c_uint64),
+                ("bt", C.c_uint64), ("lit", C.c_uint64), ("match", C.c_uint64)]
+data = corpus.fill("text", corpus.SEED_ENWIK9, 0, mib << 20).tobytes()
+p = lib.props_init(64 << 20, 3)
+w = BytesWriter()
+h = lib.lib.CSCEnc_Create(C.byref(p), C.cast(w.ptr(), C.c_void_p), None)
+lib.lib.CSCMI_EncodeHostChunk.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+t0 = time.time()
+for off in range(0, len(data), 2 << 20):
+    lib.lib.CSCMI_EncodeHostChunk(h, data[off:off + (2 << 20)], min(2 << 20, len(data) - off))
+dt = time.time() - t0
+st = St(); lib.lib.CSCMI_GetStats.argtypes = [C.c_void_p, C.c_void_p]; lib.lib.CSCMI_GetStats(h, C.byref(st))
+lib.lib.CSCMI_DebugTimers.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+tm = (C.c_uint64 * 16)(); lib.lib.CSCMI_DebugTimers(h, tm)
+names = ["node: label, m_pos", "node: wait record", "node: rep entries + lengths", "node: acceptance + price table", "node: wait literal price",
+         "node: relax + rotate", "exit: length, event, rebase", "exit: back-trace + coding", "dict filter", "window memcpy + stage"]
+tot = sum(tm)
+print(f"{len(data)/1e6/dt:.3f} MB/s, kernel {st.encode_kernel_ms:.0f} ms, nodes {st.find}, slid {st.slide}, lit {st.lit}, match {st.match}")
+for n, v in zip(names, tm):
+    if v: print(f"  {n:34s} {v/1e6:10.1f} Mcyc  {100*v/tot:5.1f}%   {v/max(1,st.find):8.0f} cyc/node")
+print(f"  total timed {tot/1e6:.1f} Mcyc over {st.encode_kernel_ms:.0f} ms -> {tot/max(1e-9,st.encode_kernel_ms*1e-3)/1e6:.0f} MHz timer")
