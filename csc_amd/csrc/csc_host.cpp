@@ -508,7 +508,7 @@ CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *outstream, ISzA
         bool ht = props->hash_bits && props->hash_width;
         if (!bt && ht && props->hash_width <= 9) e->parser |= 4;
         // level-3 geometry: the pipeline form of the advanced parser (csc_kernels_dp4.inc)
-        if ((e->parser & 4) && props->lz_mode == 3 && props->hash_width <= 2 && props->good_len >= 2 && props->good_len <= 32) e->parser |= 8;
+        if ((e->parser & 4) && props->lz_mode == 3 && props->hash_width <= 2 && props->good_len >= 2 && props->good_len <= 16) e->parser |= 8;
     }
     bool ok = hipGetDevice(&e->device) == hipSuccess;
     // each process/thread may sit on another device: the constant tables are per device

@@ -48,7 +48,7 @@ static struct {
     int la, refresh_delay, refresh_at;
     /* statistics */
     unsigned long long n_nodes, n_windows, n_slide, n_dev, n_undo_pos, n_slow, n_refresh, n_batches, n_exact_pos, n_direct_lit;
-    unsigned long long n_len_gt129, n_hdev_events;
+    unsigned long long n_len_gt129, n_hdev_events, n_repnodes, n_h0, n_h1, n_h2, n_h3p, n_a0long;
 } M;
 
 static void m3_die(const char *what) { fprintf(stderr, "m3_model: %s\n", what); abort(); }
@@ -61,12 +61,16 @@ static int m3_new_ent(uint32_t dist, uint32_t base, uint64_t mask, uint32_t cov_
     return M.nent++;
 }
 
-/* bit t: wnd[base + t] == wnd[(base + t - d) mod wnd_size], for base + t < sb_end (later bits are never used) */
+/* bit t: wnd[base + t] == wnd[base + t - d].  The mask CARRIES the reference's caps (csc_mf.cpp:268-269): no bit at or beyond the
+ * sub-block end (limit), and a mask based in front of position == distance (source wrapped to the window's end) stops there
+ * (wnd_size - cmp_pos) -- so a query is a count of trailing ones and nothing else. */
 static uint64_t m3_eq_mask(const OrcEnc *e, uint32_t base, uint32_t d, uint32_t sb_end)
 {
     uint64_t m = 0;
     for (uint32_t t = 0; t < 64 && base + t < sb_end; t++) {
-        uint32_t q = base + t, src = q >= d ? q - d : q + e->wnd_size - d;
+        uint32_t q = base + t;
+        if (base < d && q >= d) break;
+        uint32_t src = q >= d ? q - d : q + e->wnd_size - d;
         if (e->wnd[q] == e->wnd[src]) m |= 1ull << t;
     }
     return m;
@@ -85,8 +89,9 @@ static uint32_t m3_rep_len(OrcEnc *e, const M3Ent *x, uint32_t wpos, uint32_t li
     uint64_t v = ~(x->mask >> off);
     uint32_t run = v ? (uint32_t)__builtin_ctzll(v) : 64;
     if (run > 64 - off) run = 64 - off;
-    uint32_t ml = UMIN(run, climit);
-    if (off + run >= 64 && run < climit) { *slow = 1; return direct; }     /* ran off the end of the mask: extend by loads */
+    uint32_t ml = run;                                                     /* no cap here: the mask carries them */
+    if (run >= 64 - off) { *slow = 1; return direct; }                     /* reached the end of the mask: extend by loads */
+    if (x->base < d && d <= wpos) { *slow = 1; return direct; }            /* mask based in front of position == distance */
     if (ml != direct) { fprintf(stderr, "mask %u direct %u off %u d %u wpos %u base %u climit %u\n", ml, direct, off, d, wpos, x->base, climit); m3_die("eq-mask length differs from the direct compare"); }
     return ml;
 }
@@ -347,6 +352,8 @@ static void m3_adv(OrcEnc *e, uint32_t size)
                 if ((pm >> s) & 1u) if (Ls >= e->good_len) break;            /* everything after the first good_len hit is ignored */
             }
             n = (uint32_t)__builtin_popcount(pm) + has1;
+            { uint32_t rm = 0; for (uint32_t s2 = 0; s2 < 4; s2++) if (cons[s2] && L[s2] > rm) rm = L[s2];
+              if (rm >= 2) M.n_repnodes++; else { int nh = __builtin_popcount(pm >> 4); if (nh == 0) M.n_h0++; else if (nh == 1) M.n_h1++; else if (nh == 2) M.n_h2++; else M.n_h3p++; } }
             a0l = 1; a0code = 0; a0id = -1;
             if (pm) { uint32_t top = 31u - (uint32_t)__builtin_clz(pm); a0l = L[top]; a0code = code[top]; a0id = cid[top]; }
             else if (has1) { a0l = 1; a0code = 1; }
@@ -468,8 +475,8 @@ static void m3_stats_atexit(void)
 {
     if (!getenv("M3_STATS")) return;
     fprintf(stderr, "m3_model: nodes %llu windows %llu direct-literals %llu | slide events %llu (len>129: %llu, same-hash: %llu) deviations %llu undone positions %llu exact positions %llu | "
-            "batches %llu | mask refreshes %llu slow-path rep compares %llu\n",
-            M.n_nodes, M.n_windows, M.n_direct_lit, M.n_slide, M.n_len_gt129, M.n_hdev_events, M.n_dev, M.n_undo_pos, M.n_exact_pos, M.n_batches, M.n_refresh, M.n_slow);
+            "batches %llu | mask refreshes %llu slow-path rep compares %llu | nodes with a rep length >= 2: %llu, else hash candidates pushed 0/1/2/3+: %llu/%llu/%llu/%llu\n",
+            M.n_nodes, M.n_windows, M.n_direct_lit, M.n_slide, M.n_len_gt129, M.n_hdev_events, M.n_dev, M.n_undo_pos, M.n_exact_pos, M.n_batches, M.n_refresh, M.n_slow, M.n_repnodes, M.n_h0, M.n_h1, M.n_h2, M.n_h3p);
 }
 
 __attribute__((constructor)) static void m3_install(void)

@@ -25,10 +25,18 @@ dt = time.time() - t0
 st = St(); lib.lib.CSCMI_GetStats.argtypes = [C.c_void_p, C.c_void_p]; lib.lib.CSCMI_GetStats(h, C.byref(st))
 lib.lib.CSCMI_DebugTimers.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 tm = (C.c_uint64 * 16)(); lib.lib.CSCMI_DebugTimers(h, tm)
-names = ["node: label, m_pos", "node: wait record", "node: rep entries + lengths", "node: acceptance + price table", "node: wait literal price",
-         "node: relax + rotate", "exit: length, event, rebase", "exit: back-trace + coding", "dict filter", "window memcpy + stage"]
-tot = sum(tm)
+names = ["wait: slide acknowledged", "window function (DP nodes)", "-", "-", "-", "-", "exit: length, event, rebase", "exit: back-trace + coding",
+         "# deviations (undo + replay)", "# rep lengths by compare", "wait record (cyc/16)", "# record waits", "wait literal price (cyc/16)", "# literal waits", "-", "-"]
+tot = sum(tm[:8])
 print(f"{len(data)/1e6/dt:.3f} MB/s, kernel {st.encode_kernel_ms:.0f} ms, nodes {st.find}, slid {st.slide}, lit {st.lit}, match {st.match}")
-for n, v in zip(names, tm):
-    if v: print(f"  {n:34s} {v/1e6:10.1f} Mcyc  {100*v/tot:5.1f}%   {v/max(1,st.find):8.0f} cyc/node")
-print(f"  total timed {tot/1e6:.1f} Mcyc over {st.encode_kernel_ms:.0f} ms -> {tot/max(1e-9,st.encode_kernel_ms*1e-3)/1e6:.0f} MHz timer")
+for i, (n, v) in enumerate(zip(names, tm)):
+    if not v: continue
+    if n.startswith("#"): print(f"  {n:34s} {v:10d}")
+    elif "cyc/16" in n: print(f"  {n:34s} {16*v/1e6:10.1f} Mcyc   {16*v/max(1,st.find):8.0f} cyc/node")
+    else: print(f"  {n:34s} {v/1e6:10.1f} Mcyc  {100*v/tot:5.1f}%   {v/max(1,st.find):8.0f} cyc/node")
+print(f"  total timed {tot/1e6:.1f} Mcyc over {st.encode_kernel_ms:.0f} ms")
+lib.lib.CSCMI_DebugTrace.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+tr = (C.c_uint64 * 768)(); lib.lib.CSCMI_DebugTrace(h, tr)
+wn = ["label, log, record, fwd", "rep lengths", "acceptance / summary", "tables + relax candidates", "exits, literal wait", "literal edge", "requests + rotate", "-"]
+for n, v in zip(wn, tr[:8]):
+    print(f"    window: {n:30s} {16*v/1e6:10.1f} Mcyc   {16*v/max(1,st.find):8.0f} cyc/node")
