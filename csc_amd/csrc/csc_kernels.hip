@@ -132,6 +132,8 @@ struct Sc {
     EncState *S;
     EncLds *L;
     void *X;                         // Dp4X (csc_kernels_dp4.inc) when the kernel has one
+    struct CoderQ *Q;                // pipeline form: range / bit coder arithmetic runs on a wavefront of its own, fed through this queue
+    uint32_t q_head, q_room;
     gu8 *wnd;
     uint32_t wnd_size, vld_rge;
     gu32 *ht2, *ht3, *ht6, *bt_head, *bt_nodes, *p_lit, *p_delta, *mfbuf;
@@ -217,6 +219,36 @@ DEV void emit_block(Sc &c, uint32_t kind, const gu8 *buf, uint32_t size)
     c.arena_used += need;
 }
 
+// ------------------------------------------------------------------------------------------
+// Coder queue (pipeline form, csc_kernels_dp4.inc).  What the adaptive model needs from a coded bit is its probability
+// update; the carry-less range arithmetic (csc_coder.h:67-81, csc_coder.cpp:76-112) needs only (probability before the
+// update, bit) and is a serial chain of its own.  So the master wavefront only updates probabilities and queues
+//   0x80000000 | bit << 12 | p          EncodeBit's arithmetic
+//   0x40000000 | nbits << 16 | value    EncDirect16
+//   0x20000000                          Coder::Flush
+// in coding order; the coder wavefront owns low / range / cache / the two block buffers and the output arena.
+constexpr uint32_t kCoderQ = 4096;
+struct CoderQ {
+    uint32_t pub, tail, done, pad;
+    uint32_t e[kCoderQ];
+};
+DEV void q_publish(Sc &c)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    *(volatile __attribute__((address_space(3))) uint32_t *)&c.Q->pub = c.q_head;
+}
+DEV void q_push(Sc &c, uint32_t e)
+{
+    if (__builtin_expect(c.q_room == 0, 0)) {
+        q_publish(c);
+        uint32_t used;
+        while ((used = c.q_head - UNI(*(volatile __attribute__((address_space(3))) uint32_t *)&c.Q->tail)) > kCoderQ - 128u) __builtin_amdgcn_s_sleep(2);
+        c.q_room = umin(kCoderQ - 64u - used, 256u);
+    }
+    c.Q->e[c.q_head & (kCoderQ - 1)] = e;
+    c.q_head++; c.q_room--;
+}
+
 DEV void rc_put(Sc &c, uint32_t byte)
 {
     c.rc_buf[c.rc_size++] = (uint8_t)byte;
@@ -242,6 +274,7 @@ DEV void rc_shift_low(Sc &c)
 // arithmetic half of EncodeBit (csc_coder.h:67-81); p is the probability BEFORE its update
 DEV void rc_code(Sc &c, uint32_t v, uint32_t p)
 {
+    if (c.Q) { q_push(c, 0x80000000u | (v ? 0x1000u : 0u) | p); return; }
     // selects, not branches: a taken scalar branch costs a lone wavefront ~35 cycles (tools/ub/ub_issue.hip)
     const uint32_t bound = (c.rc_range >> 12) * p;
     c.rc_low += v ? 0u : bound;
@@ -267,6 +300,7 @@ DEV void bc_put(Sc &c, uint32_t byte)
 // Coder::EncDirect16, csc_coder.cpp:76-87
 DEV void enc_direct16(Sc &c, uint32_t val, uint32_t len)
 {
+    if (c.Q) { q_push(c, 0x40000000u | (len << 16) | (val & 0xFFFFu)); return; }
     c.bc_curval = (c.bc_curval << len) | val;
     c.bc_curbits += len;
     while (c.bc_curbits >= 8) {
@@ -284,6 +318,7 @@ DEV void enc_direct(Sc &c, uint32_t v, uint32_t l)   // EncodeDirect, csc_coder.
 // whatever the persistent buffer held; rc_buf is zero-initialised once.
 DEV void coder_flush(Sc &c)
 {
+    if (c.Q) { q_push(c, 0x20000000u); q_publish(c); return; }
     for (int i = 0; i < 5; i++) rc_shift_low(c);
     c.rc_size++;
     bc_put(c, (c.bc_curval << (8 - c.bc_curbits)) & 0xFF);
@@ -647,6 +682,7 @@ DEV void lz_compress_advanced_dp4(Sc &, uint32_t) {}
 DEV void d4_init(Sc &) {}
 DEV void d4_worker(Sc &) {}
 DEV void d4_quit(Sc &) {}
+DEV CoderQ *d4_coderq(Sc &) { return nullptr; }
 #endif
 #include "csc_kernels_blocks.inc"
 

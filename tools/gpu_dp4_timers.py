@@ -26,7 +26,7 @@ st = St(); lib.lib.CSCMI_GetStats.argtypes = [C.c_void_p, C.c_void_p]; lib.lib.C
 lib.lib.CSCMI_DebugTimers.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 tm = (C.c_uint64 * 16)(); lib.lib.CSCMI_DebugTimers(h, tm)
 names = ["wait: slide acknowledged", "window function (DP nodes)", "-", "-", "-", "-", "exit: length, event, rebase", "exit: back-trace + coding",
-         "# deviations (undo + replay)", "# rep lengths by compare", "wait record (cyc/16)", "# record waits", "wait literal price (cyc/16)", "# literal waits", "-", "-"]
+         "# deviations (undo + replay)", "# rep lengths by compare", "wait record (cyc/16)", "# record waits", "wait literal price (cyc/16)", "# literal waits", "# nodes on the straight-line path", "-"]
 tot = sum(tm[:8])
 print(f"{len(data)/1e6/dt:.3f} MB/s, kernel {st.encode_kernel_ms:.0f} ms, nodes {st.find}, slid {st.slide}, lit {st.lit}, match {st.match}")
 for i, (n, v) in enumerate(zip(names, tm)):
@@ -37,6 +37,9 @@ for i, (n, v) in enumerate(zip(names, tm)):
 print(f"  total timed {tot/1e6:.1f} Mcyc over {st.encode_kernel_ms:.0f} ms")
 lib.lib.CSCMI_DebugTrace.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 tr = (C.c_uint64 * 768)(); lib.lib.CSCMI_DebugTrace(h, tr)
-wn = ["label, log, record, fwd", "rep lengths", "acceptance / summary", "tables + relax candidates", "exits, literal wait", "literal edge", "requests + rotate", "-"]
-for n, v in zip(wn, tr[:8]):
+wn = ["general: record, fwd", "general: rep lengths", "general: acceptance", "general: tables + relax", "general: exits, literal wait", "general: literal edge", "general: requests + rotate", "top: label + log (all nodes)", "straight-line node body", "straight-line: requests + rotate"]
+for n, v in zip(wn, tr[:10]):
     print(f"    window: {n:30s} {16*v/1e6:10.1f} Mcyc   {16*v/max(1,st.find):8.0f} cyc/node")
+
+if tr[12]:
+    print(f"    in-situ probes ({tr[12]}): dependent LDS read {tr[10]/tr[12]:.0f} cycles (incl. 2 s_memtime), 8 dependent VALU mads + readfirstlane {tr[11]/tr[12]:.0f} cycles")

@@ -17,6 +17,9 @@ __global__ __launch_bounds__(64) void k(uint32_t *g, unsigned long long *out, ui
     __syncthreads();
     uint32_t s = RFL(seed), a = RFL(seed * 3) | 1, acc = 0;
     uint32_t v = threadIdx.x + seed, w = threadIdx.x * 7 + 1, lane = threadIdx.x & 63;
+    uint32_t rI0 = lane, rI1 = lane * 3, n_tg = 0, n_hs = 0, n_w = 0, n_lp = 0, n_fw = 0;
+    uint4 n_en = make_uint4(5, 0, 0, 0);
+    uint16_t *ldsh = (uint16_t *)lds;
     unsigned long long t0 = __builtin_readcyclecounter();
 #pragma unroll 1
     for (int i = 0; i < IT; i++) {
@@ -40,6 +43,39 @@ __global__ __launch_bounds__(64) void k(uint32_t *g, unsigned long long *out, ui
         if (MODE == 16) { R8({ uint64_t m = (((uint64_t)v << 32) | w) >> (v & 63); v = (uint32_t)__builtin_ctzll(~m | (1ull << 63)) + w; }) }   // 64-bit shift + ctz chain
         if (MODE == 17) { R8(lds[(s & 1023)] = s; s = RFL(lds[(s + 1) & 1023]) + s;) }          // uniform LDS store + dependent uniform load
         if (MODE == 18) { R8(v += 1; w += 2; acc += 3; s += a;) }                               // 8 x (2 independent VALU + 2 SALU)
+        if (MODE == 20) {
+            // replica of the DP master's straight-line node (csc_kernels_dp4.inc): label read, mask -> rep length, rare tests,
+            // one vector relax from a prefetched length table, literal edge, requests for the next node, ring rotate
+            const uint32_t s_price = RFL(v), s_bs = RFL(w), s_i0 = RFL(rI0), s_i1 = RFL(rI1);
+            const uint32_t state = (s_bs >> 16) & 63;
+            const uint32_t row = ((volatile uint16_t *)ldsh)[state * 16 + (lane & 15)];
+            const uint32_t off = (uint32_t)i - n_en.y;
+            const uint64_t m = (((uint64_t)n_en.w << 32) | n_en.z) >> (off & 63u);
+            const uint32_t room = 64u - (off & 63u);
+            const uint32_t mm = (uint32_t)__builtin_ctzll(~m | (1ull << 63));
+            const uint32_t rl = mm < room ? mm : room;
+            const bool rare_v = lane < 4 && (rl >= 2u || off >= 64u || rl >= room || n_fw != 0);
+            const uint32_t hs = RFL(n_hs);
+            const bool rare_s = RFL(n_tg) != (uint32_t)i + 7 || ((hs >> 8) & 255) >= 16;
+            const uint32_t hw = lane < 16 ? n_w : 0u;
+            const uint32_t hd = hw & 0x3FFFFFFFu;
+            const uint32_t slt = hd < 4 ? hd - 1 : 33u - (uint32_t)__builtin_clz(hd - 2);
+            const uint32_t hcost = (slt > 2u ? slt + 2u : 2u) * 128u;
+            const uint32_t cand = acc + hcost + (s_price + RDL(row, 4));
+            const bool better = hw != 0 && cand < v;
+            uint32_t nP = better ? cand : v, nB = better ? (s_bs + 1) : w, n0 = better ? (hw >> 30 | s_i0 << 16) : rI0, n1 = better ? (s_i0 >> 16 | s_i1 << 16) : rI1;
+            const uint32_t c1 = s_price + RFL(n_lp) + RDL(row, 8);
+            const bool b1 = lane == 1 && c1 < nP;
+            nP = b1 ? c1 : nP; nB = b1 ? s_bs : nB; n0 = b1 ? s_i0 : n0; n1 = b1 ? s_i1 : n1;
+            if (!rare_s && __ballot(rare_v) == 0) { v = nP; w = nB; rI0 = n0; rI1 = n1; s += hs >> 24; }
+            const uint32_t rs = ((uint32_t)i + 1) & 255;
+            n_tg = ((volatile uint32_t *)lds)[rs]; n_hs = ((volatile uint32_t *)lds)[256 + rs]; n_w = ((volatile uint32_t *)lds)[512 + rs * 8 + (lane & 7)];
+            n_lp = ((volatile uint16_t *)ldsh)[2048 + rs];
+            const uint32_t q0 = RDL(rI0, 1), q1 = RDL(rI1, 1);
+            const uint32_t rid = lane < 4 ? (__builtin_amdgcn_perm(q1, q0, 0x0C0C0100u) & 255) : 0;
+            { const volatile uint32_t *e4 = (const volatile uint32_t *)&lds4[rid]; n_en.x = e4[0]; n_en.y = e4[1]; n_en.z = e4[2]; n_en.w = e4[3]; } n_fw = ((volatile uint32_t *)lds)[3000 + rid];
+            v = DPP(0, v, 0x134); w = DPP(0, w, 0x134); rI0 = DPP(0, rI0, 0x134); rI1 = DPP(0, rI1, 0x134);
+        }
         if (MODE == 19) { R8(s = RDL(v, 3) + RDL(w, 4) + RDL(v, 9) + RDL(w, 11) + s;) v += s; } // 32 independent readlanes feeding SALU adds
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -56,15 +92,16 @@ int main()
                            "readfirstlane -> SALU -> VALU", "readlane const -> SALU -> VALU", "readlane SGPR idx -> SALU -> VALU", "ballot -> ff1 -> SALU -> VALU",
                            "dependent ds_bpermute (+add)", "dependent ds_read_b32", "dependent ds_read_b128 (+add)", "2 x wave_rol:1 (2 chains)", "s_memtime",
                            "SALU + uniform branch ~50%", "m0 writelane + SALU", "dependent v_perm (+add)", "64-bit shift + ctz chain", "uniform LDS store + load",
-                           "2 VALU + 2 SALU independent", "4 const readlanes + SALU adds"};
-    const int NM = 20;
+                           "2 VALU + 2 SALU independent", "4 const readlanes + SALU adds", "REPLICA of the DP straight-line node"};
+    const int NM = 21;
     for (int rep = 0; rep < 2; rep++) {
 #define RUN(M) hipLaunchKernelGGL(k<M>, dim3(1), dim3(64), 0, 0, g, out, 12345u + rep); (void)hipDeviceSynchronize();
-        RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18) RUN(19)
+        RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18) RUN(19) RUN(20)
     }
     (void)hipMemcpy(h, out, sizeof(unsigned long long) * NM, hipMemcpyDeviceToHost);
     const double base = h[0] / (double)IT;
     printf("%-40s %8.1f cycles/iter\n", names[0], base);
-    for (int m = 1; m < NM; m++) printf("%-40s %8.1f cycles per copy (8 copies per iteration)\n", names[m], (h[m] / (double)IT - base) / 8.0);
+    for (int m = 1; m < NM - 1; m++) printf("%-40s %8.1f cycles per copy (8 copies per iteration)\n", names[m], (h[m] / (double)IT - base) / 8.0);
+    printf("%-40s %8.1f cycles per node\n", names[NM - 1], h[NM - 1] / (double)IT);
     return 0;
 }
