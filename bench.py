@@ -323,6 +323,8 @@ def run_single(args, R, lib, src, level, dict_size):
     props = lib.props_init(min(dict_size, task_size), level)          # csa_worker.cpp:35
     chunk = int(props.raw_blocksize)
     nsteps = args.warmup + args.steps
+    if args.config != "enwik9":
+        args.steady_steps = 0        # (a 256 MiB / 1 GiB window takes minutes to fill at these levels; the headline config only)
     steady_from = max(nsteps, (int(props.dict_size) + chunk - 1) // chunk) if args.steady_steps > 0 else nsteps
     nchunks = steady_from + (args.steady_steps if args.steady_steps > 0 else 0)
     nbytes = min(task_size, nchunks * chunk)

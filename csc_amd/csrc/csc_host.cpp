@@ -31,6 +31,9 @@ void launch_encode_runs(int parser, EncState *S, const RunDesc *runs, uint32_t n
 void launch_encode_eof(EncState *S, hipStream_t st);
 void launch_encode_runs_multi(int parser, uint32_t nstreams, EncState *const *states, const RunDesc *const *runs,
                               const uint32_t *nruns, const uint32_t *reset, hipStream_t st);
+#ifdef CSCMI_STAGE_TEST
+void launch_stage_filter(EncState *S, uint32_t kind, uint32_t size, uint32_t chn, uint32_t *result, hipStream_t st);
+#endif
 }  // namespace cscmi
 
 using namespace cscmi;
@@ -733,6 +736,47 @@ void CSCMI_GetStats(CSCEncHandle p, CSCMIStats *out)
     }
     *out = e->stats;
 }
+
+#ifdef CSCMI_STAGE_TEST
+// Test-only entry points (tests/stage/libcsc_stage.so -- the same sources built with -DCSCMI_STAGE_TEST; the product library does
+// not have them): the analyzer kernel and the three forward filters on a caller-supplied buffer, one stage at a time.
+
+// out: 7 words per 8 KiB block: type, bpb, dlt_bpb[5] (csc_analyzer.cpp:184-239, :166-182)
+int CSCST_Analyze(CSCEncHandle p, const void *host, size_t size, uint32_t *out)
+{
+    EncInstance *e = (EncInstance *)p;
+    if (!e || size == 0 || size > e->props.raw_blocksize) return -1;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->h.inbuf, host, size, hipMemcpyHostToDevice, e->stream));
+    const uint32_t nblk = ((uint32_t)size + kMinBlock - 1) / kMinBlock;
+    HIPCHK(hipMemsetAsync(e->h.binfo, 0xEE, sizeof(BlockInfo) * nblk, e->stream));
+    launch_analyze(e->d_state, (uint32_t)size, e->d_entcoef, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(e->h_binfo, e->h.binfo, sizeof(BlockInfo) * nblk, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (uint32_t b = 0; b < nblk; b++) {
+        out[b * 7] = e->h_binfo[b].type; out[b * 7 + 1] = e->h_binfo[b].bpb;
+        for (int k = 0; k < 5; k++) out[b * 7 + 2 + k] = e->h_binfo[b].dlt_bpb[k];
+    }
+    return 0;
+}
+
+// kind 0 Forward_E89, 1 Foward_Dict (*result = its return value), 2 Forward_Delta with `chn` channels; buf is transformed in place
+int CSCST_Filter(CSCEncHandle p, int kind, void *buf, size_t size, uint32_t chn, uint32_t *result)
+{
+    EncInstance *e = (EncInstance *)p;
+    if (!e || size == 0 || size > e->props.raw_blocksize) return -1;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->h.inbuf, buf, size, hipMemcpyHostToDevice, e->stream));
+    launch_stage_filter(e->d_state, (uint32_t)kind, (uint32_t)size, chn, e->h.dup_flags, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(buf, e->h.inbuf, size, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->h_small, e->h.dup_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (result) *result = e->h_small[0];
+    return 0;
+}
+#endif   // CSCMI_STAGE_TEST
 
 #ifdef CSCMI_TIMERS
 // development aids (tools/gpu_timers.py, tools/gpu_trace.py): only in the -DCSCMI_TIMERS build, never in the product library

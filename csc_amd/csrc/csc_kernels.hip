@@ -391,14 +391,21 @@ DEV void encode_byte_tree(Sc &c, gu32 *row, uint32_t sym)
     for (int j = 0; j < 8; j++) rc_code(c, (cc >> (7 - j)) & 1, rdlane(pold, j));
 }
 
-// Model::EncodeLiteral, csc_model.cpp:169-183
+// Model::EncodeLiteral, csc_model.cpp:169-183.  The eight tree probabilities are requested first (an HBM / L2 round trip) and
+// the flag bit is coded while they travel.
 DEV void encode_literal(Sc &c, uint32_t sym)
 {
+    gu32 *row = c.p_lit + c.ctx * 256;
+    const uint32_t cc = sym | 0x100;
+    const uint32_t k = c.lane & 7;
+    const uint32_t idx = cc >> (8 - k), bit = (cc >> (7 - k)) & 1;
+    const uint32_t pold = row[idx];
     enc_bit_lds(c, 0, P_STATE + c.state * 3);
     c.state = (c.state * 4) & 0x3F;
-    gu32 *row = c.p_lit + c.ctx * 256;
     c.ctx = sym;
-    encode_byte_tree(c, row, sym);
+    if (c.lane < 8) row[idx] = p_update(bit, pold);
+#pragma unroll
+    for (int j = 0; j < 8; j++) rc_code(c, (cc >> (7 - j)) & 1, rdlane(pold, j));
     c.st_lit++;
 }
 

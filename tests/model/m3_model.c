@@ -36,7 +36,11 @@ typedef struct {
 typedef struct {
     M3Slot s[M3_NS];
     uint32_t h2, h3, h6;
-    uint8_t hdev;         /* h6 == h6 of the previous position, or h6 == 0: SlidePos would not shift here */
+    uint8_t hdev;
+    /* find_match's acceptance over the hash slots ALONE (minlen still 1) and FindMatchWithPrice's table for it, as the compare
+     * wavefronts precompute them: pm_h = pushed hash slots, a0l_h = the longest, len_owner[l] = hash slot + 1 that owns length l */
+    uint32_t pm_h, a0l_h;
+    uint8_t len_owner[M3_RING + 1];         /* h6 == h6 of the previous position, or h6 == 0: SlidePos would not shift here */
 } M3Rec;
 typedef struct { uint32_t dist, base, cov_end; uint64_t mask; int fwd; uint32_t req_at; } M3Ent;
 
@@ -170,6 +174,24 @@ static void m3_compare(OrcEnc *e, uint32_t i)
             q->eid = m3_new_ent(q->dist, wpos, m3_eq_mask(e, wpos, q->dist, sb_end), sb_end);
             uint32_t l = dist_slot(q->dist - 1);
             q->dcost = (l > 2 ? l + 2 : 2) * 128;
+        }
+    }
+    /* hash-only acceptance (csc_mf.cpp:301-363,453-485 with minlen 1) and its length table (:600-624) */
+    {
+        uint32_t premax = 1, prevL = 1;
+        r->pm_h = 0; r->a0l_h = 1;
+        memset(r->len_owner, 0, sizeof(r->len_owner));
+        for (uint32_t s = 0; s < 2 + W; s++) {
+            const M3Slot *q = &r->s[s];
+            const uint32_t Ls = q->cons ? q->ml : 0;
+            if (q->cons && Ls > premax && !q->drop) {
+                r->pm_h |= 1u << s;
+                for (uint32_t l = prevL + 1; l <= Ls && l <= M3_RING; l++)
+                    if (!(l <= 6 && q->dist >= kBound[l])) r->len_owner[l] = (uint8_t)(s + 1);
+                prevL = Ls; r->a0l_h = Ls;
+                if (Ls >= e->good_len) break;
+            }
+            if (Ls > premax) premax = Ls;
         }
     }
 }
@@ -352,6 +374,21 @@ static void m3_adv(OrcEnc *e, uint32_t size)
                 if ((pm >> s) & 1u) if (Ls >= e->good_len) break;            /* everything after the first good_len hit is ignored */
             }
             n = (uint32_t)__builtin_popcount(pm) + has1;
+            {
+                /* what the kernel relies on: (a) no rep length >= 2 => the node's acceptance IS the hash slots' own; (b) otherwise the
+                 * hash candidates pushed are the hash-only ones longer than the longest rep length Rmax, and every length above Rmax
+                 * keeps the owner the hash-only table gives it (lengths up to Rmax belong to rep candidates) */
+                uint32_t Rmax = 1;
+                for (uint32_t s2 = 0; s2 < 4; s2++) if (cons[s2] && L[s2] > Rmax) Rmax = L[s2];
+                int repkill = 0;
+                for (uint32_t s2 = 0; s2 < 4; s2++) if (((pm >> s2) & 1u) && L[s2] >= e->good_len) repkill = 1;
+                if (Rmax < 2 && (pm >> 4) != r->pm_h) m3_die("hash-only acceptance differs without rep candidates");
+                if (!repkill) {
+                    uint32_t expect = 0;
+                    for (uint32_t s2 = 0; s2 < NS; s2++) if (((r->pm_h >> s2) & 1u) && r->s[s2].ml > Rmax) expect |= 1u << s2;
+                    if ((pm >> 4) != expect) m3_die("pushed hash candidates are not the hash-only ones above the longest rep length");
+                }
+            }
             { uint32_t rm = 0; for (uint32_t s2 = 0; s2 < 4; s2++) if (cons[s2] && L[s2] > rm) rm = L[s2];
               if (rm >= 2) M.n_repnodes++; else { int nh = __builtin_popcount(pm >> 4); if (nh == 0) M.n_h0++; else if (nh == 1) M.n_h1++; else if (nh == 2) M.n_h2++; else M.n_h3p++; } }
             a0l = 1; a0code = 0; a0id = -1;
@@ -368,6 +405,7 @@ static void m3_adv(OrcEnc *e, uint32_t size)
                     if (!((pm >> s) & 1u)) continue;
                     for (uint32_t l = prevL + 1; l <= L[s]; l++) {
                         own[l] = s;
+                        if (s >= 4 && l <= M3_RING && !(l <= 6 && cdist[s] >= kBound[l]) && r->len_owner[l] != s - 4 + 1) m3_die("length owner differs from the hash-only table");
                         const uint32_t rdist = s < 4 ? 0 : cdist[s];
                         lane_code[l] = (l <= 6 && rdist >= kBound[l]) ? 0 : code[s];
                         lane_id[l] = cid[s];
