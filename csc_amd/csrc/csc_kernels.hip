@@ -249,6 +249,20 @@ DEV void q_push(Sc &c, uint32_t e)
     c.q_head++; c.q_room--;
 }
 
+// `n` EncodeBit entries at once: lane from + k holds decision k (its probability before the update, its bit)
+DEV void q_push_bits(Sc &c, uint32_t pold, uint32_t bit, uint32_t n, uint32_t from = 0)
+{
+    if (__builtin_expect(c.q_room < n, 0)) {
+        q_publish(c);
+        uint32_t used;
+        while ((used = c.q_head - UNI(*(volatile __attribute__((address_space(3))) uint32_t *)&c.Q->tail)) > kCoderQ - 128u) __builtin_amdgcn_s_sleep(2);
+        c.q_room = umin(kCoderQ - 64u - used, 256u);
+    }
+    const uint32_t k = c.lane - from;
+    if (k < n) c.Q->e[(c.q_head + k) & (kCoderQ - 1)] = 0x80000000u | (bit ? 0x1000u : 0u) | pold;
+    c.q_head += n; c.q_room -= n;
+}
+
 DEV void rc_put(Sc &c, uint32_t byte)
 {
     c.rc_buf[c.rc_size++] = (uint8_t)byte;
@@ -397,6 +411,24 @@ DEV void encode_literal(Sc &c, uint32_t sym)
 {
     gu32 *row = c.p_lit + c.ctx * 256;
     const uint32_t cc = sym | 0x100;
+    if (c.Q) {
+        // the flag (lane 0) and the eight decisions of the symbol's tree walk (lanes 1..8) as one gather / update / scatter and
+        // one store into the coder wavefront's queue
+        const uint32_t k = (c.lane - 1u) & 7u;
+        const uint32_t idx = cc >> (8 - k), bit = c.lane == 0 ? 0u : (cc >> (7 - k)) & 1;
+        const uint32_t fidx = P_STATE + c.state * 3;
+        uint32_t pold = 0;
+        if (c.lane == 0) pold = c.L->P[fidx];
+        else if (c.lane < 9) pold = row[idx];
+        const uint32_t pnew = p_update(bit, pold);
+        if (c.lane == 0) c.L->P[fidx] = pnew;
+        else if (c.lane < 9) row[idx] = pnew;
+        q_push_bits(c, pold, bit, 9);
+        c.state = (c.state * 4) & 0x3F;
+        c.ctx = sym;
+        c.st_lit++;
+        return;
+    }
     const uint32_t k = c.lane & 7;
     const uint32_t idx = cc >> (8 - k), bit = (cc >> (7 - k)) & 1;
     const uint32_t pold = row[idx];
@@ -467,6 +499,7 @@ DEV uint32_t dec_apply(Sc &c, const Decisions &d)
 // range-code decisions [0, to) from registers (static lane numbers), and the four of a distance's low-bits tree
 DEV void dec_code(Sc &c, uint32_t pold, uint64_t bits, uint32_t to)
 {
+    if (c.Q) { q_push_bits(c, pold, (uint32_t)(bits >> c.lane) & 1u, to); return; }
 #pragma unroll
     for (uint32_t k = 0; k < 24; k++) {
         if (k >= to) break;
@@ -475,6 +508,7 @@ DEV void dec_code(Sc &c, uint32_t pold, uint64_t bits, uint32_t to)
 }
 DEV void dec_code4(Sc &c, uint32_t pold, uint64_t bits, uint32_t from)
 {
+    if (c.Q) { q_push_bits(c, pold, (uint32_t)(bits >> c.lane) & 1u, 4, from); return; }
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) rc_code(c, (uint32_t)(bits >> (from + k)) & 1u, rdlane(pold, from + k));
 }

@@ -43,3 +43,10 @@ for n, v in zip(wn, tr[:10]):
 
 if tr[12]:
     print(f"    in-situ probes ({tr[12]}): dependent LDS read {tr[10]/tr[12]:.0f} cycles (incl. 2 s_memtime), 8 dependent VALU mads + readfirstlane {tr[11]/tr[12]:.0f} cycles")
+
+if tr[15]:
+    nd = max(1, st.find)
+    print(f"    spine: {tr[15]} windows, {16*tr[13]/nd:.0f} cyc/node in the node loop, {tr[14]} straight-line steps")
+    for b in (0, 1):
+        n = max(1, tr[18 + 3*b])
+        print(f"    edge {b}: {n} nodes, wait for label {16*tr[16+3*b]/n:.0f} cyc/node, work {16*tr[17+3*b]/n:.0f} cyc/node")
