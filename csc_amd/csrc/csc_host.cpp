@@ -790,6 +790,13 @@ void CSCMI_DebugTimers(CSCEncHandle p, uint64_t *out16)
     for (int i = 0; i < 16; i++) out16[i] = ks.tm[i];
 }
 
+void CSCMI_DebugSetMask(CSCEncHandle p, uint64_t mask)      // csc_kernels_dp4.inc: D5DBG
+{
+    EncInstance *e = (EncInstance *)p;
+    (void)hipSetDevice(e->device);
+    (void)hipMemcpy(&e->d_state->stats.trace[63][0], &mask, sizeof(mask), hipMemcpyHostToDevice);
+}
+
 void CSCMI_DebugTrace(CSCEncHandle p, uint64_t *out768)
 {
     EncInstance *e = (EncInstance *)p;
