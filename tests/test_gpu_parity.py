@@ -110,6 +110,21 @@ def test_config5_geometry_roundtrip_and_parity(prod, orc, zalloc):
     assert (rc, s) == orc.encode(data, props=orc.props_init(1 << 30, 2), alloc=zalloc)
 
 
+@pytest.mark.timeout(600)
+def test_level3_long_runs_of_windows_that_end_at_their_first_node(prod, orc, zalloc):
+    """8 MiB of the enwik9 stand-in from byte 375 000 000, -m3 -d64m.  Around 6 MiB in there is a stretch where window after
+    window of the advanced parser ends at its first node (one long match after the other); the rep distances' mask entries have
+    to be moved on to their re-based copies across those windows or they die with the candidate entries they started from
+    (csc_kernels_dp4.inc: d5_forward_ids).  Found with bench.py's -p8 tasks 3 and 5; kept as the shortest input that shows it."""
+    from csc_amd import corpus
+    data = corpus.fill("text", corpus.SEED_ENWIK9, 375000000, 8 << 20).tobytes()
+    p = prod.props_init(64 << 20, 3)
+    rc, got = prod.encode(data, props=p)
+    rc2, want = orc.encode(data, props=p, alloc=zalloc)
+    assert rc == 0 and rc2 == 0
+    assert got == want
+
+
 def test_advanced_parser_wavefront_counts(prod, orc, zalloc):
     """The advanced parser of the hash-table levels picks its form by how many streams a launch carries: <= 128 the chain form
     (eight wavefronts: chain + seven workers, csc_kernels_dp3.inc), <= 256 four parse wavefronts taking nodes in turn
