@@ -51,7 +51,7 @@ static struct {
     uint32_t sb0, pos0, size, ih, ch;
     int la, refresh_delay, refresh_at;
     /* statistics */
-    unsigned long long n_nodes, n_windows, n_slide, n_dev, n_undo_pos, n_slow, n_refresh, n_batches, n_exact_pos, n_direct_lit;
+    unsigned long long n_nodes, n_windows, n_slide, n_dev, n_undo_pos, n_slow, n_refresh, n_batches, n_exact_pos, n_direct_lit, n_split_checked;
     unsigned long long n_len_gt129, n_hdev_events, n_repnodes, n_h0, n_h1, n_h2, n_h3p, n_a0long;
 } M;
 
@@ -286,6 +286,7 @@ static void m3_slide_event(OrcEnc *e, uint32_t s, uint32_t len)
 /* ---------------------------------------------------------------------------------------------------------------- */
 /* the parser                                                                                                        */
 typedef struct { uint32_t price, dist, back, state; int id[4]; } M3Lab;
+typedef struct { uint32_t price, dist, back; } M3Shadow;
 
 static void m3_perm_ids(int *out, const int *in, uint32_t code, int newid)
 {
@@ -328,11 +329,25 @@ static void m3_adv(OrcEnc *e, uint32_t size)
         uint32_t reach = 0, k = 0, a0l = 1, a0code = 0, exit_kind = 0;
         int a0id = -1;
         M3Lab cur;
+        /* the spine + edges split of the kernel (csc_kernels_dp4.inc, d5_spine / d5_edges), shadowed: the match edges of the even
+         * and of the odd nodes go into a ring each (strict `<` in node order inside a ring); node t's label = the better of the
+         * two rings' entries by (price, source node), then node t - 1's length-1 edge if strictly better.  Asserted equal to the
+         * label of the one ring at every node. */
+        static M3Shadow sh[2][AP_LIMIT + M3_RING + 2], own[AP_LIMIT + M3_RING + 2];
+        for (uint32_t t = 0; t < aplimit + M3_RING + 2; t++) { sh[0][t].price = sh[1][t].price = own[t].price = M3_INF; }
         M.n_windows++;
         for (;; k++) {
             const uint32_t p = w0 + k, wpos = M.sb0 + p, limit = size - p;
             cur = ring[0];
             fin_dist[k] = cur.dist; fin_back[k] = cur.back;
+            if (k >= 1) {
+                const M3Shadow *A = &sh[k & 1][k], *B = &sh[(k - 1) & 1][k];
+                M3Shadow m = *A;
+                if (B->price < m.price || (B->price == m.price && B->price != M3_INF && B->back < m.back)) m = *B;
+                if (own[k].price < m.price) m = own[k];
+                if (m.price != cur.price || m.dist != cur.dist || m.back != cur.back) m3_die("spine/edge merge differs from the single ring");
+                M.n_split_checked++;
+            }
             M.n_nodes++;
             if (k == aplimit) { exit_kind = 1; break; }                       /* :271 */
             m3_ensure(e, p);
@@ -439,6 +454,7 @@ static void m3_adv(OrcEnc *e, uint32_t size)
                 const uint32_t tree = literal_price(e, cur.state, lit_ctx, e->wnd[wpos]) - lit_flag[cur.state];
                 uint32_t c1 = tree + lit_flag[cur.state] + cur.price, k1 = 0;
                 if (has1 && p1flag[cur.state] + cur.price < c1) { c1 = p1flag[cur.state] + cur.price; k1 = 1; }
+                own[k + 1].price = c1; own[k + 1].dist = k1; own[k + 1].back = k;
                 if (c1 < ring[1].price) {
                     ring[1].price = c1; ring[1].dist = k1; ring[1].back = k;
                     ring[1].state = (cur.state * 4 + (k1 ? 2u : 0u)) & 0x3F;
@@ -448,6 +464,7 @@ static void m3_adv(OrcEnc *e, uint32_t size)
             for (uint32_t l = 2; l <= a0l; l++) {
                 if (!lane_code[l]) continue;
                 const uint32_t np = lane_price[l] + cur.price;
+                if (np < sh[k & 1][k + l].price) { sh[k & 1][k + l].price = np; sh[k & 1][k + l].dist = lane_code[l]; sh[k & 1][k + l].back = k; }
                 if (np < ring[l].price) {
                     ring[l].price = np; ring[l].dist = lane_code[l]; ring[l].back = k;
                     ring[l].state = (cur.state * 4 + (lane_code[l] <= 4 ? 3u : 1u)) & 0x3F;
@@ -513,8 +530,8 @@ static void m3_stats_atexit(void)
 {
     if (!getenv("M3_STATS")) return;
     fprintf(stderr, "m3_model: nodes %llu windows %llu direct-literals %llu | slide events %llu (len>129: %llu, same-hash: %llu) deviations %llu undone positions %llu exact positions %llu | "
-            "batches %llu | mask refreshes %llu slow-path rep compares %llu | nodes with a rep length >= 2: %llu, else hash candidates pushed 0/1/2/3+: %llu/%llu/%llu/%llu\n",
-            M.n_nodes, M.n_windows, M.n_direct_lit, M.n_slide, M.n_len_gt129, M.n_hdev_events, M.n_dev, M.n_undo_pos, M.n_exact_pos, M.n_batches, M.n_refresh, M.n_slow, M.n_repnodes, M.n_h0, M.n_h1, M.n_h2, M.n_h3p);
+            "batches %llu | mask refreshes %llu slow-path rep compares %llu | nodes with a rep length >= 2: %llu, else hash candidates pushed 0/1/2/3+: %llu/%llu/%llu/%llu | spine/edge merges checked %llu\n",
+            M.n_nodes, M.n_windows, M.n_direct_lit, M.n_slide, M.n_len_gt129, M.n_hdev_events, M.n_dev, M.n_undo_pos, M.n_exact_pos, M.n_batches, M.n_refresh, M.n_slow, M.n_repnodes, M.n_h0, M.n_h1, M.n_h2, M.n_h3p, M.n_split_checked);
 }
 
 __attribute__((constructor)) static void m3_install(void)

@@ -73,3 +73,5 @@ def test_model_equals_oracle(built, knobs):
     assert int(re.search(r"deviations (\d+)", s).group(1)) > 0, s          # speculative inserts undone + replayed
     assert int(re.search(r"slide events (\d+)", s).group(1)) > 100, s
     assert int(re.search(r"mask refreshes (\d+)", s).group(1)) > 100, s
+    # every node's label was also formed the way the kernel's spine forms it (two edge rings merged by price, then source; own edge last)
+    assert int(re.search(r"spine/edge merges checked (\d+)", s).group(1)) > 100000, s
