@@ -249,6 +249,8 @@ class Rank:
             raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
         # CSC_BENCH_BACKEND=gloo (tests only): the N > 1 code path with several ranks sharing one GPU; the driver's runs use RCCL
         self.backend = os.environ.get("CSC_BENCH_BACKEND", "nccl")
+        if self.backend == "nccl" and local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py --gpus {args.gpus}: rank {self.rank} has no GPU of its own (this node shows {torch.cuda.device_count()}); one process per GPU over RCCL")
         dev = local_rank if self.backend == "nccl" else local_rank % torch.cuda.device_count()
         torch.cuda.set_device(dev)
         self.dist = None
