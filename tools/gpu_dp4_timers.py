@@ -13,7 +13,8 @@ class St(C.Structure):
     _fields_ = [("chunks", C.c_uint64), ("input_bytes", C.c_uint64), ("output_bytes", C.c_uint64), ("encode_launches", C.c_uint64),
                 ("encode_kernel_ms", C.c_double), ("analyze_kernel_ms", C.c_double), ("find", C.c_uint64), ("slide", C.c_uint64),
                 ("bt", C.c_uint64), ("lit", C.c_uint64), ("match", C.c_uint64)]
-data = corpus.fill("text", corpus.SEED_ENWIK9, 0, mib << 20).tobytes()
+kind = sys.argv[2] if len(sys.argv) > 2 else "text"
+data = corpus.fill(kind, corpus.SEED_ENWIK9, 0, mib << 20).tobytes()
 p = lib.props_init(64 << 20, 3)
 w = BytesWriter()
 h = lib.lib.CSCEnc_Create(C.byref(p), C.cast(w.ptr(), C.c_void_p), None)
