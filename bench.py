@@ -381,7 +381,7 @@ def run_single(args, R, lib, src, level, dict_size):
     for f, _ in CSCMIStats._fields_:
         setattr(ds, f, getattr(s1, f) - getattr(s0, f))
     bpl = in_b / max(1, launches)
-    line["roofline"] = roofline(level, ratio, launches, kern_ms, in_b, "k_encode_runs",
+    line["roofline"] = roofline(level, ratio, launches, kern_ms, in_b, "k_encode_runs_dp4" if level == 3 else "k_encode_runs",
                                 "one stream = one workgroup: the libcsc chain is latency/issue-bound, not bandwidth-bound",
                                 traffic_from_profile(f"m{level}_d{args.dict}_single_stream", bpl), ds)
     line["counters"] = {"find_match_calls": int(ds.find_match_calls), "slide_positions": int(ds.slide_positions),
@@ -521,7 +521,7 @@ def run_split(args, R, lib, src, level, dict_size, split, steps, warmup):
         line["ms_per_step"] = round(tmax * 1e3 / max(1, steps), 3)
         # launch count and HIP-event kernel time accrue on the batch's lead handle only, so the sums are the lead's
         line["roofline"] = roofline(level, ratio, s1.encode_launches - s0.encode_launches, s1.encode_kernel_ms - s0.encode_kernel_ms,
-                                    (s1.input_bytes - s0.input_bytes), "k_encode_runs_multi*",
+                                    (s1.input_bytes - s0.input_bytes), "k_encode_runs_multi_dp4" if level == 3 else "k_encode_runs_multi*",
                                     f"rank 0's GPU: {S} streams per launch, one workgroup each; per-launch time from HIP events on the launch stream")
         line["tasks_per_rank"] = [len(a) for a in tasks.assign(slices, R.world)]
         line["tasks"] = [dict(task=t, **merged[t]) for t in sorted(merged)]
