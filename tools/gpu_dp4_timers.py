@@ -26,7 +26,7 @@ dt = time.time() - t0
 st = St(); lib.lib.CSCMI_GetStats.argtypes = [C.c_void_p, C.c_void_p]; lib.lib.CSCMI_GetStats(h, C.byref(st))
 lib.lib.CSCMI_DebugTimers.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 tm = (C.c_uint64 * 16)(); lib.lib.CSCMI_DebugTimers(h, tm)
-names = ["wait: slide acknowledged", "window function (DP nodes)", "-", "-", "-", "-", "exit: length, event, rebase", "exit: back-trace + coding",
+names = ["wait: slide acknowledged", "window function (DP nodes)", "exit: back-trace", "-", "-", "-", "exit: length, event, rebase", "exit: back-trace + coding",
          "# deviations (undo + replay)", "# rep lengths by compare", "wait record (cyc/16)", "# record waits", "wait literal price (cyc/16)", "# literal waits", "# nodes on the straight-line path", "-"]
 tot = sum(tm[:8])
 print(f"{len(data)/1e6/dt:.3f} MB/s, kernel {st.encode_kernel_ms:.0f} ms, nodes {st.find}, slid {st.slide}, lit {st.lit}, match {st.match}")
@@ -51,3 +51,10 @@ if tr[15]:
     for b in (0, 1):
         n = max(1, tr[18 + 3*b])
         print(f"    edge {b}: {n} nodes, wait for label {16*tr[16+3*b]/n:.0f} cyc/node, work {16*tr[17+3*b]/n:.0f} cyc/node")
+
+if tr[15]:
+    nw = tr[15]
+    print(f"    spine per window ({nw} windows, {st.find/nw:.1f} nodes each): prologue {16*tr[24]/nw:.0f}, until label 1 is out {16*tr[25]/nw:.0f}, "
+          f"poll waits {16*tr[26]/nw:.0f}, general steps {16*tr[27]/nw:.0f} ({tr[28]/nw:.2f} of them, {16*tr[27]/max(1,tr[28]):.0f} each), last iteration {16*tr[29]/nw:.0f}, epilogue {16*tr[30]/nw:.0f}, loop total {16*tr[13]/nw:.0f}")
+    for i, n in enumerate(names[:8]):
+        if tm[i]: print(f"    per window: {n:34s} {tm[i]/nw:8.0f}")
