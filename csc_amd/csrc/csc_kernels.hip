@@ -113,6 +113,7 @@ struct EncLds {
             };
             uint8_t fin_lit[kAPLimit + 3];
         };
+        uint32_t fin2[(kAPLimit + 1) * 2];                                  // level-3 pipeline form (csc_kernels_dp4.inc): its log, {distance code, back | state << 16} per node
         struct { uint16_t trie_next[300 * 26]; uint8_t trie_sym[304]; };     // word trie, only while the dictionary filter runs
         struct {   // lazy levels: parse wavefront -> coder wavefront (see "token pipe"); the control words sit behind the
                    // ring, i.e. beyond the 15.9 KiB the word trie uses, because the coder wavefront polls them while the

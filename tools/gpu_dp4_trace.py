@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Development aid (-DCSCMI_TIMERS build): cycle stamps of the spine and the edge wavefronts over the nodes of ONE DP window of
+the level-3 pipeline form.  gpurun -- python tools/gpu_dp4_trace.py [window numbers ...]"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa
+from csc_amd import corpus
+from csc_amd.capi import CscLib, BytesWriter
+lib = CscLib(os.path.join(ROOT, "csc_amd", "csrc", "build", "dev", "libcsc_mi355x_timers.so"))
+kind = os.environ.get("KIND", "text")
+data = corpus.fill(kind, corpus.SEED_ENWIK9, 0, 2 << 20).tobytes()
+p = lib.props_init(64 << 20, 3)
+lib.lib.CSCMI_EncodeHostChunk.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+lib.lib.CSCMI_DebugSetMask.argtypes = [C.c_void_p, C.c_uint64]
+lib.lib.CSCMI_DebugTrace.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+for win in [int(a) for a in sys.argv[1:]] or [3000]:
+    w = BytesWriter()
+    h = lib.lib.CSCEnc_Create(C.byref(p), C.cast(w.ptr(), C.c_void_p), None)
+    lib.lib.CSCMI_DebugSetMask(h, win << 32)
+    lib.lib.CSCMI_EncodeHostChunk(h, data, len(data))
+    tr = (C.c_uint64 * 768)(); lib.lib.CSCMI_DebugTrace(h, tr)
+    rows = [[tr[(4 + k) * 12 + e] for e in range(12)] for k in range(50)]
+    rows = [r for r in rows if r[0] or r[4]]
+    if not rows: print(f"window {win}: nothing"); continue
+    t0 = min(v for r in rows for v in (r[0], r[4]) if v)
+    print(f"window {win}: {len(rows)} nodes.  spine: top, poll begins, poll ends, label k+1 out (or general step ends) | edge: top, label seen, done, path (1 straight 2 rep 3 general)")
+    f = lambda v: f"{v - t0:7d}" if v else "      -"
+    for k, r in enumerate(rows):
+        print(f"{k:3d}  {f(r[0])} {f(r[8])} {f(r[1])} {f(r[2])} {f(r[3])} | {f(r[4])} {f(r[5])} {f(r[6])} {r[7]}")
