@@ -72,13 +72,10 @@ def alg_bytes(level, ratio, stats=None):
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a child torchrun (this process has not imported
     torch or touched HIP) and relay rank 0's line.  Never exec: the box refuses an exec from a process that initialised the GPU."""
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    # --standalone: torchrun picks a free rendezvous port itself (no bind-then-close probe that another launcher could race)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={n}",
+           os.path.abspath(__file__)] + argv
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     for l in p.stdout.splitlines():
@@ -89,6 +86,68 @@ def spawn_ranks(n, argv):
         sys.exit(p.returncode or 1)
     print(lines[-1], flush=True)
     sys.exit(0)
+
+
+def host_info():
+    """host model + core count for the cpu_baseline objects"""
+    model = "unknown"
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                model = l.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 1
+    return {"host_cpu": model, "nproc": os.cpu_count() or 1, "usable_cores": usable}
+
+
+def _cpu_task(job):
+    """one task of the split through the reference (a process of its own: the reference's worker threads share nothing either)"""
+    name, seed_kind, off, nbytes, level, dict_size, task_size = job
+    from csc_amd import corpus
+    from csc_amd.capi import CscLib
+    src = corpus.Source(name)
+    data = src.read(off, nbytes).tobytes()
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libcsc_ref.so")
+    orc_path = os.path.join(ROOT, "oracle", "liborc.so")
+    lib = CscLib(ref_path if os.path.exists(ref_path) else orc_path)
+    za = None
+    if os.path.exists(orc_path):
+        o = C.CDLL(orc_path)
+        o.orc_zero_alloc.restype = C.c_void_p
+        za = o.orc_zero_alloc()
+    props = lib.props_init(min(dict_size, task_size), level)
+    t0 = time.perf_counter()
+    rc, stream = lib.encode(data, props=props, alloc=za)
+    return rc, len(data), len(stream), time.perf_counter() - t0
+
+
+def cpu_baseline_split(src, slices, level, dict_size, sample_bytes):
+    """the -p<S> line's CPU leg: min(8, tasks) worker processes of the reference (csarc -t8: csarc.cpp:200-201, one libcsc
+    stream per task, csa_worker.cpp:23-56), each over the first `sample_bytes` of its task, started together"""
+    import multiprocessing as mp
+    hi = host_info()
+    workers = min(8, len(slices), hi["usable_cores"])
+    jobs = [(src.name, None, off, min(n, sample_bytes), level, dict_size, n) for off, n in slices[:8]]
+    kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libcsc_ref.so")) else "port"
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(workers) as pool:
+        res = pool.map(_cpu_task, jobs)
+    dt = time.perf_counter() - t0
+    assert all(r[0] == 0 for r in res)
+    tot = sum(r[1] for r in res)
+    out = dict(value=round(tot / 1e6 / dt, 3), unit="MB/s", cores=workers, kind=kind,
+               sample=f"first {jobs[0][3]} bytes of each of the first {len(jobs)} tasks of the split, {workers} worker processes at once "
+                      f"(the reference runs min(8, tasks) worker threads, csarc.cpp:200-201), same CSCProps per task, "
+                      f"{'oracle/_ref (reference sources, g++ -O4)' if kind == 'reference' else 'oracle/liborc.so (C port)'}; wall-clock incl. process start",
+               seconds=round(dt, 2), ratio=round(sum(r[2] for r in res) / max(1, tot), 4),
+               per_worker_MBps=[round(r[1] / 1e6 / r[3], 3) for r in res])
+    out.update(hi)
+    return out
 
 
 def cpu_baseline(data, level, dict_size, task_size):
@@ -108,10 +167,12 @@ def cpu_baseline(data, level, dict_size, task_size):
     rc, stream = lib.encode(data, props=props, alloc=za)
     dt = time.perf_counter() - t0
     assert rc == 0
-    return {"value": round(len(data) / 1e6 / dt, 3), "unit": "MB/s", "cores": 1, "kind": kind,
-            "sample": f"first {len(data)} bytes of the same stream, same CSCProps, 1 thread, "
-                      f"{'oracle/_ref (reference sources, g++ -O4)' if kind == 'reference' else 'oracle/liborc.so (C port)'}",
-            "seconds": round(dt, 2), "ratio": round(len(stream) / max(1, len(data)), 4)}, stream
+    out = {"value": round(len(data) / 1e6 / dt, 3), "unit": "MB/s", "cores": 1, "kind": kind,
+           "sample": f"first {len(data)} bytes of the same stream, same CSCProps, 1 thread, "
+                     f"{'oracle/_ref (reference sources, g++ -O4)' if kind == 'reference' else 'oracle/liborc.so (C port)'}",
+           "seconds": round(dt, 2), "ratio": round(len(stream) / max(1, len(data)), 4)}
+    out.update(host_info())
+    return out, stream
 
 
 def decode_all(lib, streams, whole, slices, width=256):
@@ -377,6 +438,9 @@ def run_single(args, R, lib, src, level, dict_size):
                      + (" (BASELINE.json configs[1])" if args.config == "enwik9" else f" (BASELINE.json config '{args.config}')")
                      + f"; step = one {chunk}-byte chunk (CSCEncoder::Compress), input resident in HBM; timed chunks {args.warmup}..{nsteps - 1}",
                      props, ratio)
+    # N = 1 default: ONE stream (BASELINE configs[1]).  The N > 1 lines belong to another curve ("p8": the archiver's task split,
+    # the same eight tasks at every N); its N = 1 point is the `p8_on_one_gpu` object of this line / `--split 8`.
+    line["curve"] = "single_stream"
     ds = CSCMIStats()
     for f, _ in CSCMIStats._fields_:
         setattr(ds, f, getattr(s1, f) - getattr(s0, f))
@@ -504,7 +568,8 @@ def run_split(args, R, lib, src, level, dict_size, split, steps, warmup):
             te = time.perf_counter() - te
             if R.rank == 0:
                 ok = all(len(got[r]) == meta[r][0] and hashlib.sha256(got[r]).hexdigest() == meta[r][1] for r in range(R.world))
-                exchange = {"what": "encoded task streams of all ranks -> rank 0 (all_gather of lengths + grouped RCCL send/recv of device tensors)",
+                how = "grouped RCCL send/recv of device tensors over xGMI" if R.backend == "nccl" else f"{R.backend} send/recv of host tensors (test backend, ranks sharing a GPU)"
+                exchange = {"what": f"encoded task streams of all ranks -> rank 0 (all_gather of lengths + {how})", "backend": R.backend,
                             "ok": bool(ok), "bytes": int(sum(m[0] for m in meta)), "seconds": round(te, 4)}
         except Exception as e:      # never lose the bench line to the hand-over
             exchange = {"ok": False, "error": repr(e)[:300]}
@@ -518,6 +583,7 @@ def run_split(args, R, lib, src, level, dict_size, split, steps, warmup):
                          f"ONE launch per rank (one workgroup per stream), inputs resident in HBM; timed chunks {warmup}..{nsteps - 1} of every task",
                          props, ratio)
         line["steps"], line["warmup"] = steps, warmup
+        line["curve"] = f"p{split}"            # which scaling curve this point belongs to: the same tasks at every N (strong scaling)
         line["ms_per_step"] = round(tmax * 1e3 / max(1, steps), 3)
         # launch count and HIP-event kernel time accrue on the batch's lead handle only, so the sums are the lead's
         line["roofline"] = roofline(level, ratio, s1.encode_launches - s0.encode_launches, s1.encode_kernel_ms - s0.encode_kernel_ms,
@@ -547,6 +613,7 @@ def main():
     ap.add_argument("--split", type=int, default=0, help="task split: 0 = one stream at N = 1, -p8 at N > 1; S > 0 = the -p<S> tasks of the file at any N")
     ap.add_argument("--steady-steps", type=int, default=3, help="N = 1 single stream: also time this many chunks after the window has filled (0 = skip)")
     ap.add_argument("--cpu-sample-mib", type=int, default=48)
+    ap.add_argument("--cpu-split-sample-mib", type=int, default=24, help="-p8 line's CPU leg: bytes of each task every reference worker process encodes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exchange", action="store_true",
                     help="N > 1: skip the RCCL hand-over of the encoded streams to rank 0 (outside the timed region)")
@@ -584,6 +651,12 @@ def main():
                 p8 = run_split(args, R, lib, src, level, dict_size, 8, args.p8_steps, 1)
                 line["p8_on_one_gpu"] = {k: p8[k] for k in ("value", "unit", "ratio", "ms_per_step", "steps", "warmup", "roofline", "bit_exact_vs_reference", "tasks_per_rank")}
                 line["p8_on_one_gpu"]["what"] = p8["config"]["workload"]
+                line["p8_on_one_gpu"]["curve"] = "p8"
+                if not args.no_cpu_baseline:
+                    try:
+                        line["p8_on_one_gpu"]["cpu_baseline"] = cpu_baseline_split(src, corpus.task_slices(src.size, 8), level, dict_size, args.cpu_split_sample_mib << 20)
+                    except Exception as e:          # never lose the bench line to the CPU leg
+                        line["p8_on_one_gpu"]["cpu_baseline"] = {"error": repr(e)[:300]}
             if args.multi_streams:
                 # extra field, not `value`: every task of the -p<S> split at once on this one GPU
                 line.update(multi_stream_job(lib, src, [int(x) for x in args.multi_streams.split(",")], level, dict_size))
