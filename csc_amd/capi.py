@@ -187,7 +187,7 @@ class CscLib:
     def encode(self, data, level: int = 2, dict_size: int = 64000000, *, props: Optional[CSCProps] = None,
                alloc=None, max_read: Optional[int] = None, writer: Optional[BytesWriter] = None,
                progress: Optional[Callable[[int, int], None]] = None, clamp_dict: bool = True,
-               reader: Optional[BytesReader] = None):
+               reader: Optional[BytesReader] = None, after_create: Optional[Callable[[int], None]] = None):
         """props -> Create -> caller writes the 10-byte header -> Encode -> Flush -> Destroy.
         Returns (rc, stream_bytes).  `clamp_dict` mirrors csa_worker.cpp:35 / csc.cpp:133-134."""
         n = len(data)
@@ -200,6 +200,8 @@ class CscLib:
         if not h:
             raise MemoryError("CSCEnc_Create returned NULL")
         w.out += self.write_properties(props)
+        if after_create is not None:
+            after_create(h)          # (tests: a development hook of a test-only library gets the handle before the first byte)
         prog = None
         pfn = None
         if progress is not None:

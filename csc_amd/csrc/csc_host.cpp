@@ -776,6 +776,17 @@ int CSCST_Filter(CSCEncHandle p, int kind, void *buf, size_t size, uint32_t chn,
     if (result) *result = e->h_small[0];
     return 0;
 }
+// the match finder's position counter (EncState::pos; MatchFinder::Init leaves it at vld_rge_ over zeroed tables): a start close to
+// 0xFFFFFFF0 brings the renormalisation of csc_mf.cpp:108-114 within reach of a test.  Right after CSCEnc_Create.
+int CSCST_SetPos(CSCEncHandle p, uint32_t pos)
+{
+    EncInstance *e = (EncInstance *)p;
+    if (!e) return -1;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(&e->d_state->pos, &pos, sizeof(pos), hipMemcpyHostToDevice));
+    return 0;
+}
 #endif   // CSCMI_STAGE_TEST
 
 #ifdef CSCMI_TIMERS

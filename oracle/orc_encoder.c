@@ -1526,6 +1526,13 @@ static void enc_free_all(OrcEnc *e)
     a->Free(a, e);
 }
 
+/* Test hook (tests/test_gpu_parity.py::test_pos_renormalisation...): start the match finder's position counter somewhere else.
+ * MatchFinder::Init leaves pos_ = vld_rge_ over zeroed tables (csc_mf.cpp:56-57,81); any larger start is the same situation --
+ * every table entry reads as out of range -- and brings normalize() (csc_mf.cpp:108-114, pos_ >= 0xFFFFFFF0) within reach of
+ * a test instead of 3.2 GB into a stream.  Call right after CSCEnc_Create. */
+void orc_debug_set_pos(CSCEncHandle h, uint32_t pos) { ((OrcEnc *)h)->pos = pos; }
+uint32_t orc_debug_get_pos(CSCEncHandle h) { return ((OrcEnc *)h)->pos; }
+
 CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *os, ISzAlloc *alloc) /* csc_enc.cpp:114-133 */
 {
     if (alloc == NULL) alloc = &g_default_alloc;

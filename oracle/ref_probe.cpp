@@ -12,8 +12,21 @@
 #include <csc_analyzer.h>
 #include <csc_filters.h>
 #include <csc_default_alloc.h>
+/* the encoder's match finder sits behind two `private:` sections (CSCEncoder::lz_, LZ::mf_); MatchFinder::pos_ itself is public */
+#define private public
+#include <csc_encoder_main.h>
+#undef private
+
+/* csc_enc.cpp:8-14 keeps this struct to itself; a CSCEncHandle points at one */
+struct ProbeEncInstance { CSCEncoder *encoder; MemIO *io; ISzAlloc *alloc; uint32_t raw_blocksize; };
 
 extern "C" {
+
+/* Start the REFERENCE's position counter somewhere else (right after CSCEnc_Create: the tables are zeroed, every entry reads as out
+ * of range whatever pos_ is) -- so that MatchFinder::normalize (csc_mf.cpp:108-114, pos_ >= 0xFFFFFFF0) runs inside a test-sized
+ * input and the goldens of tools/make_golden_renorm.py pin the restatement's and the HIP path's version of it. */
+void ref_debug_set_pos(void *h, uint32_t pos) { ((ProbeEncInstance *)h)->encoder->lz_.mf_.pos_ = pos; }
+uint32_t ref_debug_get_pos(void *h) { return ((ProbeEncInstance *)h)->encoder->lz_.mf_.pos_; }
 
 uint32_t ref_analyze_block(uint8_t *src, uint32_t size, uint32_t *bpb)
 {

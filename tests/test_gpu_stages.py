@@ -96,3 +96,33 @@ def test_enwik8_standin_level1_against_the_oracle(prod, orc, zalloc):
     assert rc == 0 and rc2 == 0 and got == want
     rcd, back = prod.decode(got)
     assert rcd == 0 and back == data
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4, 5])
+def test_pos_renormalisation_is_reached_and_matches_the_oracle(level, orc, zalloc):
+    """MatchFinder::normalize (csc_mf.cpp:108-114) runs when pos_ reaches 0xFFFFFFF0 -- 3.2 GB into a stream, beyond every BASELINE
+    config.  Started 300 000 positions short of it (a development hook on both sides: orc_debug_set_pos in the oracle port,
+    CSCST_SetPos in the test-only build of the product), the counter crosses the line in the middle of 1 MiB: every table is
+    rebased there, and at level 3 the pipeline form hands over to its one-wavefront fallback from 0xFFFF0000 on.  Same bytes."""
+    import torch  # noqa: F401
+    from csc_amd.capi import CscLib
+    lib = CscLib(os.path.join(ROOT, "tests", "stage", "libcsc_stage.so"))
+    lib.lib.CSCST_SetPos.argtypes = [C.c_void_p, C.c_uint32]
+    lib.lib.CSCST_SetPos.restype = C.c_int
+    orc.lib.orc_debug_set_pos.argtypes = [C.c_void_p, C.c_uint32]
+    orc.lib.orc_debug_set_pos.restype = None
+    start = 0xFFFFFFF0 - 300000
+    data = cases.build([["text", 77, 0, 500000], ["exe", 78, 0, 300000], ["text", 77, 100000, 248576]])      # (= renorm.json's spec)
+    props = lib.props_init(1 << 20, level)
+    rc, got = lib.encode(data, props=props, after_create=lambda h: lib.lib.CSCST_SetPos(h, start))
+    rc2, want = orc.encode(data, props=props, alloc=zalloc, after_create=lambda h: orc.lib.orc_debug_set_pos(h, start))
+    assert rc == 0 and rc2 == 0
+    assert got == want, (level, len(got), len(want))
+    # ... and what the REFERENCE writes from the same start (tests/golden/renorm.json, recorded through oracle/ref_probe.cpp)
+    import hashlib
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "renorm.json")))
+    assert gold["start"] == start and gold["dict"] == 1 << 20
+    g = gold["levels"][str(level)]
+    assert len(got) == g["stream_bytes"] and hashlib.sha256(got).hexdigest() == g["sha256"]
+    rcd, back = lib.decode(got)
+    assert rcd == 0 and back == data

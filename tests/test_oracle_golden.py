@@ -123,3 +123,27 @@ def test_multi_stream_digest_fixture_is_wellformed():
         assert len(corpus.task_slices(g["total"], want)) == want
         e = g["splits"][str(want)]
         assert len(e["sha256_of_stream_sha256s"]) == 64 and 0.2 < e["stream_bytes"] / g["total"] < 0.3
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4, 5])
+def test_oracle_pos_renormalisation_matches_the_reference(orc, zalloc, level):
+    """MatchFinder::normalize (csc_mf.cpp:108-114): the restatement with its position counter started 300 000 positions short of
+    0xFFFFFFF0 writes what the REFERENCE writes from the same start (tests/golden/renorm.json, tools/make_golden_renorm.py through
+    oracle/ref_probe.cpp::ref_debug_set_pos) -- which is the stream of an ordinary start: a correct rebase is invisible."""
+    import ctypes as C
+    import hashlib
+    import json
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "renorm.json")))
+    orc.lib.orc_debug_set_pos.argtypes = [C.c_void_p, C.c_uint32]
+    orc.lib.orc_debug_set_pos.restype = None
+    orc.lib.orc_debug_get_pos.argtypes = [C.c_void_p]
+    orc.lib.orc_debug_get_pos.restype = C.c_uint32
+    data = cases.build(gold["spec"])
+    props = orc.props_init(gold["dict"], level)
+    ends = []
+    rc, got = orc.encode(data, props=props, alloc=zalloc, after_create=lambda h: orc.lib.orc_debug_set_pos(h, gold["start"]))
+    assert rc == 0
+    want = gold["levels"][str(level)]
+    assert len(got) == want["stream_bytes"] and hashlib.sha256(got).hexdigest() == want["sha256"]
+    rc, plain = orc.encode(data, props=props, alloc=zalloc)
+    assert rc == 0 and plain == got

@@ -15,8 +15,10 @@ class St(C.Structure):
     _fields_ = [("chunks", C.c_uint64), ("input_bytes", C.c_uint64), ("output_bytes", C.c_uint64), ("encode_launches", C.c_uint64),
                 ("encode_kernel_ms", C.c_double), ("analyze_kernel_ms", C.c_double), ("find", C.c_uint64), ("slide", C.c_uint64),
                 ("bt", C.c_uint64), ("lit", C.c_uint64), ("match", C.c_uint64)]
-data = corpus.fill("text", corpus.SEED_ENWIK9, 0, mib << 20).tobytes()
-p = lib.props_init(64 << 20, level)
+KIND = os.environ.get("KIND", "text")
+SEED = {"text": corpus.SEED_ENWIK9, "exe": corpus.SEED_EXE, "mix5": corpus.SEED_EXE, "silesia": 6, "delta": corpus.SEED_DELTA}.get(KIND, 1)
+data = corpus.fill(KIND, SEED, int(os.environ.get("OFFSET", "0")), mib << 20).tobytes()
+p = lib.props_init(int(os.environ.get("DICT_MIB", "64")) << 20, level)
 w = BytesWriter()
 h = lib.lib.CSCEnc_Create(C.byref(p), C.cast(w.ptr(), C.c_void_p), None)
 lib.lib.CSCMI_EncodeHostChunk.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
