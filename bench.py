@@ -602,6 +602,83 @@ def run_split(args, R, lib, src, level, dict_size, split, steps, warmup):
     return line
 
 
+def run_tree(args, R, spec):
+    """`--workload tree`: the many-task curve.  A seeded tree of thousands of files (csc_amd/treegen.py) goes through the archiver
+    path end to end -- plan (csarc.cpp:490-557), one libcsc stream per extension group, container + index -- with the tasks dealt
+    over the ranks (csc_amd/sharded.py: task i of the dispatch order -> rank i mod N, ONE exchange: the encoded tasks to rank 0).
+    A step = one whole `csarc a -r -m3 -d64m` of the tree; the archive's SHA-256 is checked against what the REFERENCE archiver
+    wrote for the same tree (tests/golden/tree_workload.json).  Inputs are files: host reads + H2D copies are inside the time."""
+    import tempfile
+    from csc_amd import sharded, treegen, csa
+    root = os.environ.get("CSC_TREE_DIR") or os.path.join(tempfile.gettempdir(), f"csc_tree_{spec}_{os.getuid()}")
+    if R.rank == 0:
+        os.makedirs(root, exist_ok=True)
+        total = treegen.materialize(root, spec)
+    R.barrier()
+    total = treegen.total_bytes(spec)
+    level, dict_size = 3, 64 << 20
+    arc = os.path.join(root, "out.csa")
+    cwd = os.getcwd()
+    os.chdir(root)                                  # names in the archive are relative to the tree's root, as in the golden run
+    try:
+        def step():
+            if R.rank == 0 and os.path.exists("out.csa"):
+                os.unlink("out.csa")
+            rc, st = sharded.add("out.csa", ["t"], level=level, dict_size=dict_size, recurse=True, overwrite=True)
+            if rc != 0:
+                raise SystemExit(f"sharded add failed rc={rc}")
+            return st
+        for _ in range(args.warmup):
+            step()
+        R.barrier()
+        t0 = time.perf_counter()
+        st = None
+        for _ in range(args.steps):
+            st = step()
+        R.barrier()
+        dt = time.perf_counter() - t0
+    finally:
+        os.chdir(cwd)
+    tmax = R.reduce(dt, "MAX")
+    line = None
+    if R.rank == 0:
+        h = hashlib.sha256()
+        with open(arc, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 22), b""):
+                h.update(blk)
+        gold = (golden("tree_workload.json") or {}).get("trees", {}).get(spec)
+        asize = os.path.getsize(arc)
+        props = csc_props_for(level, dict_size)
+        line = {
+            "metric": f"archive-create MB/s (10^6 input bytes / wall-clock) on the seeded {spec} workload, csarc a -r -m{level} -d{dict_size >> 20}m; archive bit-exact vs reference (-t1 layout)",
+            "value": round(total * args.steps / 1e6 / tmax, 4), "unit": "MB/s", "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(tmax * 1e3 / max(1, args.steps), 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8/u32 (byte + 32-bit integer work; 12-bit probabilities, 64-bit range-coder low)",
+            "data": f"synthetic (csc_amd/treegen.py '{spec}': {len(treegen.files(spec))} files, {total} bytes, corpus kinds text/exe/delta/silesia)",
+            "curve": spec,
+            "config": {"workload": f"{spec}: {len(treegen.files(spec))} files in {st.get('n_tasks', '?')} tasks (one per 4-character extension, csarc.cpp:545-557), the same tasks at every N, "
+                                   f"task i of the size-sorted dispatch order -> rank i mod N (csarc.cpp:355), every rank's tasks concurrently on its GPU (one workgroup per "
+                                   f"stream), encoded tasks -> rank 0 over {'RCCL/xGMI' if R.backend == 'nccl' else R.backend}, rank 0 writes container + index; "
+                                   f"step = one whole archive; files read from {root} (page cache), H2D inside the timed region",
+                       "tasks": st.get("n_tasks"), "files": len(treegen.files(spec)), **props},
+            "ratio": round(asize / max(1, total), 4), "archive_bytes": asize, "archive_sha256": h.hexdigest(),
+            "bit_exact_vs_reference": None if not gold else bool(gold["sha256"] == h.hexdigest() and gold["archive_bytes"] == asize),
+            "roofline": {"bound": "hbm", "achieved": round(alg_bytes(level, asize / max(1, total)) * total * args.steps / tmax / 1e9, 4), "peak": HBM_PEAK_GBS * R.world,
+                         "unit": "GB/s", "frac": round(alg_bytes(level, asize / max(1, total)) * total * args.steps / tmax / 1e9 / (HBM_PEAK_GBS * R.world), 8),
+                         "traffic": None, "note": "whole job incl. host I/O: algorithmic bytes of the LZ pass / wall-clock against N x 8 TB/s; kernels: k_encode_runs_multi* (one workgroup per task stream)"},
+            "cpu_baseline": None,
+        }
+        if gold:
+            line["cpu_reference_seconds_recorded"] = gold.get("reference_seconds")
+    return line
+
+
+def csc_props_for(level, dict_size):
+    import csc_amd
+    p = csc_amd.load().props_init(dict_size, level)
+    return {"dict_size": int(p.dict_size), "hash_bits": int(p.hash_bits), "hash_width": int(p.hash_width), "good_len": int(p.good_len), "lz_mode": int(p.lz_mode), "bt_size": int(p.bt_size)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -619,6 +696,9 @@ def main():
                     help="N > 1: skip the RCCL hand-over of the encoded streams to rank 0 (outside the timed region)")
     ap.add_argument("--multi-streams", default="127,954",
                     help="extra (N = 1, enwik9 only): the WHOLE file as -p<S> task splits, all tasks concurrently on this GPU; '' = skip")
+    ap.add_argument("--workload", default="stream", choices=["stream", "tree", "tree_small"],
+                    help="stream: the libcsc stream workloads above (default).  tree: the many-task curve -- a seeded tree of 4096 files / 2048 extension "
+                         "groups (2.1 GB) through the archiver path end to end, tasks dealt over the ranks (csc_amd/sharded.py); tree_small: 256 files (tests)")
     ap.add_argument("--p8-steps", type=int, default=2, help="extra (N = 1, enwik9 only): the N > 1 workload (-p8) on this one GPU for this many steps; 0 = skip")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -641,7 +721,9 @@ def main():
     src = corpus.Source(name)
 
     split = args.split if args.split > 0 else (8 if R.world > 1 else 0)
-    if split:
+    if args.workload != "stream":
+        line = run_tree(args, R, args.workload)
+    elif split:
         line = run_split(args, R, lib, src, level, dict_size, split, args.steps, args.warmup)
     else:
         line = run_single(args, R, lib, src, level, dict_size)

@@ -238,13 +238,23 @@ DEV void q_publish(Sc &c)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     *(volatile __attribute__((address_space(3))) uint32_t *)&c.Q->pub = c.q_head;
 }
+// wait until at most kCoderQ - `need` entries are outstanding; -> entries outstanding.  Bounded: a coder wavefront that has stopped
+// consuming turns into an error code (0x40200000 | ...) instead of a hung kernel
+constexpr uint32_t ERR_QUEUE_STALL = 0x40200000u;
+DEV uint32_t q_wait_room(Sc &c, uint32_t need)
+{
+    uint32_t used, spins = 0;
+    while ((used = c.q_head - UNI(*(volatile __attribute__((address_space(3))) uint32_t *)&c.Q->tail)) > kCoderQ - need) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 24)) { if (!c.error) c.error = ERR_QUEUE_STALL | (used & 0xFFFFu); return 0; }
+    }
+    return used;
+}
 DEV void q_push(Sc &c, uint32_t e)
 {
     if (__builtin_expect(c.q_room == 0, 0)) {
         q_publish(c);
-        uint32_t used;
-        while ((used = c.q_head - UNI(*(volatile __attribute__((address_space(3))) uint32_t *)&c.Q->tail)) > kCoderQ - 128u) __builtin_amdgcn_s_sleep(2);
-        c.q_room = umin(kCoderQ - 64u - used, 256u);
+        c.q_room = umin(kCoderQ - 64u - q_wait_room(c, 128u), 256u);
     }
     c.Q->e[c.q_head & (kCoderQ - 1)] = e;
     c.q_head++; c.q_room--;
@@ -255,9 +265,7 @@ DEV void q_push_bits(Sc &c, uint32_t pold, uint32_t bit, uint32_t n, uint32_t fr
 {
     if (__builtin_expect(c.q_room < n, 0)) {
         q_publish(c);
-        uint32_t used;
-        while ((used = c.q_head - UNI(*(volatile __attribute__((address_space(3))) uint32_t *)&c.Q->tail)) > kCoderQ - 128u) __builtin_amdgcn_s_sleep(2);
-        c.q_room = umin(kCoderQ - 64u - used, 256u);
+        c.q_room = umin(kCoderQ - 64u - q_wait_room(c, 128u), 256u);
     }
     const uint32_t k = c.lane - from;
     if (k < n) c.Q->e[(c.q_head + k) & (kCoderQ - 1)] = 0x80000000u | (bit ? 0x1000u : 0u) | pold;

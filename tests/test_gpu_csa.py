@@ -358,3 +358,18 @@ def test_bench_multi_rank_path_two_processes(tmp_path):
     assert {t["rank"] for t in d["tasks"]} == {0, 1} and all(t["chunks"] == 2 for t in d["tasks"])
     assert d["exchange"]["ok"] is True and d["exchange"]["bytes"] > 0
     assert 0 < d["value"] < 1000 and d["roofline"]["launches"] == 1 and d["roofline"]["frac"] > 0
+
+
+def test_bench_tree_workload_small_archive_equals_reference(tmp_path):
+    """bench.py --workload tree_small end to end (128 tasks through CSA add on the GPU): the line says the archive is the one the
+    REFERENCE archiver wrote for the tree (tests/golden/tree_workload.json)"""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, CSC_TREE_DIR=str(tmp_path))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tree_small", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["bit_exact_vs_reference"] is True and line["curve"] == "tree_small" and line["config"]["tasks"] == 128
+    assert line["value"] > 0 and line["scaling"] == "strong"

@@ -230,3 +230,32 @@ def test_oracle_archive_matches_reference(case, codec, tmp_path, monkeypatch):
             assert data == content[name], name
     if case == "single_shadowed_by_empty":
         assert info["abindex"] == {} and info["index"]["q/a.bin"]["frags"] == []      # the reference stores nothing here
+
+
+def test_tree_workload_is_deterministic_and_splits_per_extension():
+    """csc_amd/treegen.py (bench.py --workload tree): names, sizes and kinds follow from the file number alone; two files per
+    4-character extension, every group >= 64 KiB, so the multi-file split (csarc.cpp:545-557) makes one task per group"""
+    from csc_amd import treegen
+    for spec, (n, per, base, spread) in treegen.SPECS.items():
+        fs = treegen.files(spec)
+        assert len(fs) == n and fs == treegen.files(spec)
+        exts = {}
+        for rel, kind, seed, size in fs:
+            assert base <= size < base + spread and kind in treegen.KINDS
+            exts.setdefault(rel.rsplit(".", 1)[1], []).append(size)
+        assert len(exts) == n // per and all(len(e) == 4 for e in exts) and all(sum(v) > 64 * 1024 for v in exts.values())
+    assert treegen.total_bytes("tree") > 2 * 10 ** 9 and len(treegen.files("tree")) >= 4096
+
+
+def test_oracle_archive_of_the_small_tree_matches_reference(codec, tmp_path, monkeypatch):
+    """the container oracle over the 128-task tree == what csarc_ref a -r -m3 -d64m -t1 wrote (tests/golden/tree_workload.json)"""
+    from csc_amd import treegen
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "tree_workload.json")))["trees"]["tree_small"]
+    enc, dec = codec
+    assert treegen.materialize(str(tmp_path), "tree_small") == gold["input_bytes"]
+    monkeypatch.chdir(tmp_path)
+    arc = orc_csa.create("out.csa", ["t"], encode=enc, level=3, dict_size=64 << 20, recurse=True)
+    import hashlib
+    assert len(arc) == gold["archive_bytes"] and hashlib.sha256(arc).hexdigest() == gold["sha256"]
+    info = orc_csa.parse(arc, dec)
+    assert len(info["abindex"]) == 128          # one task per extension group
