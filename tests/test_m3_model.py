@@ -59,7 +59,9 @@ print("MODEL_OK", n)
 
 
 @pytest.mark.parametrize("knobs", [
-    {},                                                              # the kernel's setting: look-ahead 192, masks re-based after 16 positions
+    {},                                                              # the model's defaults: look-ahead 192, masks re-based after 16 positions, 6 positions late
+    {"M3_LA": 112, "M3_REFRESH_AT": 32, "M3_REFRESH_DELAY": 16},     # the kernel's constants (csc_kernels_dp4.inc): kD4LA 48 + one batch of 64 ahead, kD4RefreshAt 32,
+                                                                     # a re-based mask taken up at the spine's next look at its ids (every 16th node)
     {"M3_LA": 1, "M3_REFRESH_DELAY": 0},                             # inserter in lock step with the parser
     {"M3_LA": 250, "M3_REFRESH_DELAY": 60, "M3_REFRESH_AT": 30},     # service far behind: rep lengths mostly by direct compare
 ])
