@@ -668,6 +668,7 @@ def run_tree(args, R, spec):
                          "traffic": None, "note": "whole job incl. host I/O: algorithmic bytes of the LZ pass / wall-clock against N x 8 TB/s; kernels: k_encode_runs_multi* (one workgroup per task stream)"},
             "cpu_baseline": None,
         }
+        line["last_step_stats_rank0"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()}
         if gold:
             line["cpu_reference_seconds_recorded"] = gold.get("reference_seconds")
     return line
@@ -696,7 +697,7 @@ def main():
                     help="N > 1: skip the RCCL hand-over of the encoded streams to rank 0 (outside the timed region)")
     ap.add_argument("--multi-streams", default="127,954",
                     help="extra (N = 1, enwik9 only): the WHOLE file as -p<S> task splits, all tasks concurrently on this GPU; '' = skip")
-    ap.add_argument("--workload", default="stream", choices=["stream", "tree", "tree_small"],
+    ap.add_argument("--workload", default="stream", choices=["stream", "tree", "tree_mid", "tree_small"],
                     help="stream: the libcsc stream workloads above (default).  tree: the many-task curve -- a seeded tree of 4096 files / 2048 extension "
                          "groups (2.1 GB) through the archiver path end to end, tasks dealt over the ranks (csc_amd/sharded.py); tree_small: 256 files (tests)")
     ap.add_argument("--p8-steps", type=int, default=2, help="extra (N = 1, enwik9 only): the N > 1 workload (-p8) on this one GPU for this many steps; 0 = skip")

@@ -233,6 +233,13 @@ struct EncInstance {
     uint32_t pend_a, pend_b;
     bool pend_first;
     int pend_ev;
+    // the run segmentation of the chunk in hand, resumable (seg_advance): it stops where LZ::IsDuplicateBlock must look at the tables
+    // as the runs so far leave them (csc_encoder_main.cpp:123-126), so that a batch of streams can take that step together
+    struct Seg {
+        uint32_t nruns, launched, last_type, last_begin, last_size, bpb, dup_from, dup_to, blk, i, need_blk, need_cnt;
+        bool first_launch;
+        int ev_used;
+    } seg;
 };
 // argument arrays of the multi-stream launch ([4 * kMaxBatch] pointer-sized words: states, run lists, run
 // counts, reset flags), one set per calling thread and device, kept for the life of the thread
@@ -332,38 +339,47 @@ int chunk_begin(EncInstance *e, const void *src, size_t size, bool on_device)
     return 0;
 }
 
-int chunk_segment(EncInstance *e, size_t size, bool defer_final)
+// start the segmentation of the chunk chunk_begin has uploaded: waits for the analyzer's verdicts
+int seg_begin(EncInstance *e)
 {
-    const uint32_t csize = (uint32_t)size;
-    const uint32_t nblk = (csize + kMinBlock - 1) / kMinBlock;
     const bool use_filters = (e->props.DLTFilter + e->props.EXEFilter + e->props.TXTFilter) != 0;
     HIPCHK(hipStreamSynchronize(e->stream));
     if (use_filters) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, e->ev_an[0], e->ev_an[1]) == hipSuccess) e->stats.analyze_kernel_ms += ms;
     }
+    EncInstance::Seg &g = e->seg;
+    g = EncInstance::Seg();
+    g.first_launch = true;
+    g.last_type = DT_NORMAL;
+    return 0;
+}
 
-    uint32_t nruns = 0, launched = 0;
-    bool first_launch = true;
-    int ev_used = 0;
-    uint32_t last_type = DT_NORMAL, last_begin = 0, last_size = 0, bpb = 0;
-    // IsDuplicateBlock results are valid only against the table state they were computed on
-    uint32_t dup_from = 0, dup_to = 0;   // blocks [dup_from, dup_to) tested since the last launch
-
+// Walk the chunk's blocks on (CSCEncoder::Compress, csc_encoder_main.cpp:85-147).  Returns 1 when block g.need_blk (and the
+// g.need_cnt - 1 blocks behind it that may need the same) must be tested by IsDuplicateBlock against the tables as the runs
+// [g.launched, g.nruns) leave them: the caller launches those runs, then k_dup_check, reads the flags back (h_dup), sets
+// g.launched = g.nruns, g.dup_from / g.dup_to, and calls again.  Returns 0 when the run list is complete.
+int seg_advance(EncInstance *e, size_t size)
+{
+    EncInstance::Seg &g = e->seg;
+    const uint32_t csize = (uint32_t)size;
+    const uint32_t nblk = (csize + kMinBlock - 1) / kMinBlock;
+    const bool use_filters = (e->props.DLTFilter + e->props.EXEFilter + e->props.TXTFilter) != 0;
     auto close_run = [&](uint32_t tail) {
-        RunDesc &r = e->h_runs[nruns++];
-        r.type = last_type; r.offset = last_begin; r.size = last_size; r.tail = tail;
+        RunDesc &r = e->h_runs[g.nruns++];
+        r.type = g.last_type; r.offset = g.last_begin; r.size = g.last_size; r.tail = tail;
     };
-
-    for (uint32_t blk = 0, i = 0; i < csize; blk++) {
-        uint32_t cur = csize - i < kMinBlock ? csize - i : kMinBlock;
+    while (g.i < csize) {
+        const uint32_t blk = g.blk;
+        uint32_t cur = csize - g.i < kMinBlock ? csize - g.i : kMinBlock;
         uint32_t this_type = DT_NORMAL;
         const BlockInfo *bi = use_filters ? &e->h_binfo[blk] : nullptr;
+        uint32_t bpb = g.bpb;
         if (use_filters) {
             this_type = bi->type;
             if (this_type != DT_SKIP) bpb = bi->bpb;
         }
-        if (this_type == DT_SKIP) this_type = last_type;
+        if (this_type == DT_SKIP) this_type = g.last_type;
         if (this_type != DT_NORMAL) {
             if (this_type == DT_EXE && e->props.EXEFilter == 0) this_type = DT_NORMAL;
             else if (this_type == DT_ENGTXT && e->props.TXTFilter == 0) this_type = DT_NORMAL;
@@ -372,38 +388,54 @@ int chunk_segment(EncInstance *e, size_t size, bool defer_final)
         if (this_type >= DT_DLT && (double)bi->dlt_bpb[this_type - DT_DLT] >= bpb * 0.95)   // :117-121
             this_type = DT_NORMAL;
         if (this_type >= DT_NO_LZ) {   // :123-126 LZ::IsDuplicateBlock against the tables as of the pending run
-            if (!(launched == nruns && blk >= dup_from && blk < dup_to)) {
-                int rc = launch_runs(e, launched, nruns, first_launch, ev_used);
-                if (rc) return rc;
-                launched = nruns;
+            if (!(g.launched == g.nruns && blk >= g.dup_from && blk < g.dup_to)) {
                 uint32_t cnt = 1;   // test the whole stretch of blocks that may need it under this state
                 while (blk + cnt < nblk && (e->h_binfo[blk + cnt].type >= DT_NO_LZ)) cnt++;
-                launch_dup_check(e->d_state, csize, blk, cnt, e->stream);
-                HIPCHK(hipGetLastError());
-                HIPCHK(hipMemcpyAsync(e->h_dup + blk, e->h.dup_flags + blk, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost, e->stream));
-                HIPCHK(hipStreamSynchronize(e->stream));
-                dup_from = blk; dup_to = blk + cnt;
+                g.need_blk = blk; g.need_cnt = cnt;
+                return 1;           // (nothing of this block has been committed: the walk resumes at it)
             }
             if (e->h_dup[blk]) this_type = DT_NORMAL;
         }
-        if (last_type != this_type || last_size + cur > e->props.raw_blocksize) {
-            if (last_size) close_run(0);
-            last_begin = i;
-            last_size = 0;
+        g.bpb = bpb;
+        if (g.last_type != this_type || g.last_size + cur > e->props.raw_blocksize) {
+            if (g.last_size) close_run(0);
+            g.last_begin = g.i;
+            g.last_size = 0;
         }
-        last_type = this_type;
-        last_size += cur;
-        i += cur;
+        g.last_type = this_type;
+        g.last_size += cur;
+        g.i += cur;
+        g.blk++;
     }
-    if (last_size) close_run(1);
+    if (g.last_size) { close_run(1); g.last_size = 0; }
+    return 0;
+}
+
+int chunk_segment(EncInstance *e, size_t size, bool defer_final)
+{
+    int rc = seg_begin(e);
+    if (rc) return rc;
+    EncInstance::Seg &g = e->seg;
+    const uint32_t csize = (uint32_t)size;
+    while ((rc = seg_advance(e, size)) == 1) {
+        rc = launch_runs(e, g.launched, g.nruns, g.first_launch, g.ev_used);
+        if (rc) return rc;
+        g.launched = g.nruns;
+        launch_dup_check(e->d_state, csize, g.need_blk, g.need_cnt, e->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(e->h_dup + g.need_blk, e->h.dup_flags + g.need_blk, sizeof(uint32_t) * g.need_cnt, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        g.dup_from = g.need_blk; g.dup_to = g.need_blk + g.need_cnt;
+    }
+    if (rc < 0) return rc;
     e->stats.chunks++;
     e->stats.input_bytes += size;
     if (defer_final) {
-        e->pend_a = launched; e->pend_b = nruns; e->pend_first = first_launch; e->pend_ev = ev_used;
+        e->pend_a = g.launched; e->pend_b = g.nruns; e->pend_first = g.first_launch; e->pend_ev = g.ev_used;
         return 0;
     }
-    int rc = launch_runs(e, launched, nruns, first_launch, ev_used);
-    e->pend_ev = ev_used;
+    rc = launch_runs(e, g.launched, g.nruns, g.first_launch, g.ev_used);
+    e->pend_ev = g.ev_used;
     return rc;
 }
 
@@ -648,35 +680,80 @@ int CSCMI_EncodeDeviceChunkBatch(int n, CSCEncHandle *hs, const void *const *dev
     void **const d_batch = t_batch.d, **const h_batch = t_batch.h;
     int rc = 0;
     for (int i = 0; i < n && !rc; i++) rc = sizes[i] ? chunk_begin((EncInstance *)hs[i], device_ptrs[i], sizes[i], true) : 0;
-    for (int i = 0; i < n && !rc; i++) rc = sizes[i] ? chunk_segment((EncInstance *)hs[i], sizes[i], true) : 0;
+    for (int i = 0; i < n && !rc; i++) rc = sizes[i] ? seg_begin((EncInstance *)hs[i]) : 0;
     if (rc) return rc;
-    // one launch per parser flavour over every handle that still has runs pending
-    for (int parser = 2; parser <= 15; parser++) {
-        if ((parser & 3) < 2) continue;
-        uint32_t m = 0;
-        EncState **st = (EncState **)h_batch;
-        const RunDesc **rl = (const RunDesc **)(h_batch + kMaxBatch);
-        uint32_t *cnt = (uint32_t *)(h_batch + 2 * kMaxBatch);
-        uint32_t *rst = (uint32_t *)(h_batch + 3 * kMaxBatch);
+    // Rounds: every stream's run segmentation goes on until it needs an IsDuplicateBlock verdict (csc_encoder_main.cpp:123-126: the
+    // runs so far must have been encoded first) or is complete.  The streams that wait for a verdict have their runs so far
+    // launched TOGETHER (one launch per parser flavour, one workgroup per stream), then their duplicate checks, one wait for all;
+    // the last round launches what is left of every stream.  (Stream by stream -- as CSCEnc_Encode does it for one handle -- a
+    // batch of streams with high-entropy / delta blocks ran one workgroup at a time.)
+    std::vector<uint8_t> state(n, 0);                // 0 walking, 1 waits for a verdict, 2 run list complete
+    for (;;) {
+        bool any_wait = false, all_done = true;
         for (int i = 0; i < n; i++) {
+            if (!sizes[i] || state[i] == 2) continue;
             EncInstance *e = (EncInstance *)hs[i];
-            if (!sizes[i] || e->parser != parser || e->pend_a == e->pend_b) continue;
-            HIPCHK(hipMemcpyAsync(e->d_runs + e->pend_a, e->h_runs + e->pend_a, sizeof(RunDesc) * (e->pend_b - e->pend_a),
-                                  hipMemcpyHostToDevice, lead->stream));
-            st[m] = e->d_state; rl[m] = e->d_runs + e->pend_a; cnt[m] = e->pend_b - e->pend_a; rst[m] = e->pend_first ? 1u : 0u;
-            m++;
+            int r = seg_advance(e, sizes[i]);
+            if (r < 0) return r;
+            state[i] = r == 1 ? 1 : 2;
+            any_wait = any_wait || r == 1;
         }
-        if (!m) continue;
-        HIPCHK(hipMemcpyAsync(d_batch, h_batch, sizeof(void *) * 4 * kMaxBatch, hipMemcpyHostToDevice, lead->stream));
-        HIPCHK(hipEventRecord(lead->ev[0][0], lead->stream));
-        launch_encode_runs_multi(parser, m, (EncState *const *)d_batch, (const RunDesc *const *)(d_batch + kMaxBatch),
-                                 (const uint32_t *)(d_batch + 2 * kMaxBatch), (const uint32_t *)(d_batch + 3 * kMaxBatch), lead->stream);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(lead->ev[0][1], lead->stream));
+        for (int i = 0; i < n; i++) all_done = all_done && (!sizes[i] || state[i] == 2);
+        // this round's launches: the waiting streams' runs so far, or -- last round -- everybody's remaining runs
+        for (int parser = 2; parser <= 15; parser++) {
+            if ((parser & 3) < 2) continue;
+            uint32_t m = 0;
+            EncState **st = (EncState **)h_batch;
+            const RunDesc **rl = (const RunDesc **)(h_batch + kMaxBatch);
+            uint32_t *cnt = (uint32_t *)(h_batch + 2 * kMaxBatch);
+            uint32_t *rst = (uint32_t *)(h_batch + 3 * kMaxBatch);
+            for (int i = 0; i < n; i++) {
+                EncInstance *e = (EncInstance *)hs[i];
+                if (!sizes[i] || e->parser != parser) continue;
+                if (!(all_done || state[i] == 1)) continue;
+                EncInstance::Seg &g = e->seg;
+                if (g.launched == g.nruns) continue;
+                HIPCHK(hipMemcpyAsync(e->d_runs + g.launched, e->h_runs + g.launched, sizeof(RunDesc) * (g.nruns - g.launched),
+                                      hipMemcpyHostToDevice, lead->stream));
+                st[m] = e->d_state; rl[m] = e->d_runs + g.launched; cnt[m] = g.nruns - g.launched; rst[m] = g.first_launch ? 1u : 0u;
+                g.launched = g.nruns; g.first_launch = false;
+                m++;
+            }
+            if (!m) continue;
+            HIPCHK(hipMemcpyAsync(d_batch, h_batch, sizeof(void *) * 4 * kMaxBatch, hipMemcpyHostToDevice, lead->stream));
+            HIPCHK(hipEventRecord(lead->ev[0][0], lead->stream));
+            launch_encode_runs_multi(parser, m, (EncState *const *)d_batch, (const RunDesc *const *)(d_batch + kMaxBatch),
+                                     (const uint32_t *)(d_batch + 2 * kMaxBatch), (const uint32_t *)(d_batch + 3 * kMaxBatch), lead->stream);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(lead->ev[0][1], lead->stream));
+            HIPCHK(hipStreamSynchronize(lead->stream));          // (the pointer tables are reused by the next flavour / round)
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, lead->ev[0][0], lead->ev[0][1]) == hipSuccess) lead->stats.encode_kernel_ms += ms;
+            lead->stats.encode_launches++;
+        }
+        if (all_done) break;
+        // the verdicts the waiting streams asked for, all in flight before the one wait
+        for (int i = 0; i < n; i++) {
+            if (!sizes[i] || state[i] != 1) continue;
+            EncInstance *e = (EncInstance *)hs[i];
+            EncInstance::Seg &g = e->seg;
+            launch_dup_check(e->d_state, (uint32_t)sizes[i], g.need_blk, g.need_cnt, lead->stream);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(e->h_dup + g.need_blk, e->h.dup_flags + g.need_blk, sizeof(uint32_t) * g.need_cnt, hipMemcpyDeviceToHost, lead->stream));
+        }
         HIPCHK(hipStreamSynchronize(lead->stream));
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, lead->ev[0][0], lead->ev[0][1]) == hipSuccess) lead->stats.encode_kernel_ms += ms;
-        lead->stats.encode_launches++;
+        for (int i = 0; i < n; i++) {
+            if (!sizes[i] || state[i] != 1) continue;
+            EncInstance::Seg &g = ((EncInstance *)hs[i])->seg;
+            g.dup_from = g.need_blk; g.dup_to = g.need_blk + g.need_cnt;
+            state[i] = 0;
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        if (!sizes[i]) continue;
+        EncInstance *e = (EncInstance *)hs[i];
+        e->stats.chunks++;
+        e->stats.input_bytes += sizes[i];
     }
     for (int i = 0; i < n; i++) {
         if (!sizes[i]) continue;

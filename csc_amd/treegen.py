@@ -15,6 +15,7 @@ MTIME = 1700000000
 KINDS = ("text", "exe", "delta", "silesia")
 SPECS = {   # name -> (files, files per extension, base size, size spread)
     "tree": (4096, 2, 384 << 10, 256 << 10),        # 2048 tasks, ~2.1 GB
+    "tree_mid": (1024, 2, 384 << 10, 256 << 10),    # 512 tasks, ~0.5 GB (development)
     "tree_small": (256, 2, 96 << 10, 64 << 10),     # 128 tasks, ~32 MB (tests)
 }
 
