@@ -300,6 +300,80 @@ def test_batch_of_streams_equals_one_by_one(prod):
         assert bytes(w.out) == prod.encode(d, 3, len(d))[1]
 
 
+@pytest.mark.parametrize("level", [3, 2])
+def test_batch_with_duplicate_block_checks_equals_oracle(prod, orc, zalloc, level):
+    """A batch whose streams hold high-entropy, delta and mixed blocks: every such block needs LZ::IsDuplicateBlock against the
+    tables "as of the pending run" (csc_encoder_main.cpp:123-126), which the batch takes in rounds (seg_advance: the waiting
+    streams' runs in one launch, their duplicate checks, one wait).  24 streams, different stopping points per stream, two
+    chunks each; every stream == the oracle's."""
+    import time
+    import torch
+    from csc_amd.capi import BytesWriter
+    L = prod.lib
+    L.CSCMI_EncodeDeviceChunkBatch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    specs = []
+    for i in range(24):
+        k = i % 6
+        if k == 0: spec = [["delta", 300 + i, 0, 700000 + 8192 * i]]
+        elif k == 1: spec = [["text", 300 + i, 0, 200000], ["random", 300 + i, 0, 50000], ["text", 300 + i, 0, 200000], ["random", 300 + i, 0, 50000]]   # the second text / random part is a duplicate
+        elif k == 2: spec = [["silesia", 300 + i, 0, 2097152 + 100000]]
+        elif k == 3: spec = [["entropy8", 300 + i, 0, 150000], ["exe", 300 + i, 0, 300000], ["delta", 300 + i, 0, 100000 + 4096 * i]]
+        elif k == 4: spec = [["text", 300 + i, 0, 900000]]
+        else: spec = [["random", 300 + i, 0, 40000], ["delta", 300 + i, 0, 60000], ["random", 300 + i, 0, 40000], ["text", 300 + i, 0, 30000 + i]]
+        specs.append(spec)
+    datas = [cases.build(sp) for sp in specs]
+    hs, ws, devs = [], [], []
+    for d in datas:
+        p = prod.props_init(len(d), level)
+        w = BytesWriter()
+        h = L.CSCEnc_Create(C.byref(p), C.cast(w.ptr(), C.c_void_p), None)
+        assert h
+        w.out += prod.write_properties(p)
+        hs.append(h); ws.append(w)
+        devs.append(torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda())
+    torch.cuda.synchronize()
+    n = len(hs)
+    H = (C.c_void_p * n)(*hs)
+    t0 = time.time()
+    for k in range(2):
+        Z = [max(0, min(2097152, len(d) - k * 2097152)) for d in datas]
+        P = (C.c_void_p * n)(*[t.data_ptr() + k * 2097152 for t in devs])
+        assert L.CSCMI_EncodeDeviceChunkBatch(n, H, P, (C.c_size_t * n)(*Z)) == 0
+    dt = time.time() - t0
+    for h in hs:
+        assert L.CSCEnc_Encode_Flush(h) == 0
+        L.CSCEnc_Destroy(h)
+    for i, (d, w) in enumerate(zip(datas, ws)):
+        rc, want = orc.encode(d, level, len(d), alloc=zalloc)
+        assert rc == 0 and bytes(w.out) == want, (i, len(w.out), len(want))
+    # (one stream at a time this took ~0.2 s per delta / silesia stream and chunk; together the whole batch is a few seconds)
+    assert dt < 30, dt
+
+
+def test_id_guard_holds_with_a_slow_service_wavefront(orc, zalloc):
+    """Round 2's review: nothing stopped an equality-mask id from outliving its entry if the service wavefront fell behind.  The
+    development build (-DCSCMI_TIMERS, csc_amd/csrc/build/dev) can slow the service wavefront by ~50 k cycles per round: re-based
+    masks then arrive dozens of nodes late, the spine's d5_refresh_ids has to WAIT for them (counter > 0), and the stream is
+    still the oracle's."""
+    import torch  # noqa: F401
+    import sys
+    dev = os.path.join(ROOT, "csc_amd", "csrc", "build", "dev", "libcsc_mi355x_timers.so")
+    if not os.path.exists(dev):
+        pytest.skip("development build not present (make -C csc_amd/csrc dev)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gpu_dp4_guard as G
+    from csc_amd import corpus
+    from csc_amd.capi import CscLib
+    lib = CscLib(dev)
+    total_waits = 0
+    for data, dsz in ((corpus.fill("text", corpus.SEED_ENWIK9, 0, 1 << 20).tobytes(), 64 << 20),
+                      (cases.build(cases.STREAM_CASES["window_wrap_32k"][0]), cases.STREAM_CASES["window_wrap_32k"][1])):
+        ok, waits, _ = G.run(lib, orc, zalloc, data, dsz, 512)
+        assert ok
+        total_waits += waits
+    assert total_waits > 0
+
+
 # ---- decode path (k_decode_run through CSCDec_*) ----
 @pytest.mark.parametrize("name,level", [("mix_types", 3), ("text_300k", 2), ("exe_300k", 5), ("delta_200k", 1),
                                         ("window_wrap_32k", 3), ("periodic_5000x200", 4), ("empty", 3), ("one_byte", 5)])

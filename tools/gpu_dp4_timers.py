@@ -27,7 +27,7 @@ st = St(); lib.lib.CSCMI_GetStats.argtypes = [C.c_void_p, C.c_void_p]; lib.lib.C
 lib.lib.CSCMI_DebugTimers.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 tm = (C.c_uint64 * 16)(); lib.lib.CSCMI_DebugTimers(h, tm)
 names = ["wait: slide acknowledged", "window function (DP nodes)", "exit: back-trace", "-", "-", "-", "exit: length, event, rebase", "exit: back-trace + coding",
-         "# deviations (undo + replay)", "# rep lengths by compare", "wait record (cyc/16)", "# record waits", "wait literal price (cyc/16)", "# literal waits", "# nodes on the straight-line path", "-"]
+         "# deviations (undo + replay)", "# rep lengths by compare", "wait record (cyc/16)", "# record waits", "wait literal price (cyc/16)", "# literal waits", "# nodes on the straight-line path", "# waits for a re-based mask (id guard)"]
 tot = sum(tm[:8])
 print(f"{len(data)/1e6/dt:.3f} MB/s, kernel {st.encode_kernel_ms:.0f} ms, nodes {st.find}, slid {st.slide}, lit {st.lit}, match {st.match}")
 for i, (n, v) in enumerate(zip(names, tm)):
