@@ -368,7 +368,7 @@ def test_id_guard_holds_with_a_slow_service_wavefront(orc, zalloc):
     total_waits = 0
     for data, dsz in ((corpus.fill("text", corpus.SEED_ENWIK9, 0, 1 << 20).tobytes(), 64 << 20),
                       (cases.build(cases.STREAM_CASES["window_wrap_32k"][0]), cases.STREAM_CASES["window_wrap_32k"][1])):
-        ok, waits, _ = G.run(lib, orc, zalloc, data, dsz, 512)
+        ok, waits, _ = G.run(lib, orc, zalloc, data, dsz, 1 << 63)
         assert ok
         total_waits += waits
     assert total_waits > 0

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stress of the id guard (csc_kernels_dp4.inc: d5_refresh_ids) in the -DCSCMI_TIMERS build: the service wavefront is slowed by
-~50 k cycles per round (debug mask bit 512), so re-based masks arrive dozens of nodes late; the spine must then WAIT for them
+~50 k cycles per round (debug mask bit 63), so re-based masks arrive dozens of nodes late; the spine must then WAIT for them
 instead of letting an id outlive its entry.  The streams must still be the oracle's, with the guard's wait counter > 0.
 make -C csc_amd/csrc dev;  gpurun -- python tools/gpu_dp4_guard.py"""
 import ctypes as C, os, sys, time
@@ -45,7 +45,7 @@ if __name__ == "__main__":
                             ("exe 512 KiB", corpus.fill("exe", corpus.SEED_EXE, 0, 1 << 19).tobytes(), 64 << 20),
                             ("window_wrap_32k", cases.build(cases.STREAM_CASES["window_wrap_32k"][0]), cases.STREAM_CASES["window_wrap_32k"][1]),
                             ("periodic", cases.build(cases.STREAM_CASES["periodic_5000x200"][0]), 1 << 20)):
-        for mask in (0, 512):
+        for mask in (0, 1 << 63):
             ok, waits, dt = run(lib, orc, za, data, dsz, mask)
             print(f"{name:18s} service {'slowed' if mask else 'normal'}: {'bit-exact' if ok else 'DIFF'}, guard waits {waits}, {len(data)/1e6/dt:.3f} MB/s", flush=True)
             allok &= ok
