@@ -58,3 +58,6 @@ if tr[15]:
           f"poll waits {16*tr[26]/nw:.0f}, general steps {16*tr[27]/nw:.0f} ({tr[28]/nw:.2f} of them, {16*tr[27]/max(1,tr[28]):.0f} each), last iteration {16*tr[29]/nw:.0f}, epilogue {16*tr[30]/nw:.0f}, loop total {16*tr[13]/nw:.0f}")
     for i, n in enumerate(names[:8]):
         if tm[i]: print(f"    per window: {n:34s} {tm[i]/nw:8.0f}")
+
+if tr[15] and any(tr[32:36]):
+    print(f"    straight line left because: mask too old / based ahead {tr[32]}, mask's last bit {tr[33]}, straddles position == distance {tr[34]}, refresh zone {tr[35]}   (general steps in all: {tr[28]})")
