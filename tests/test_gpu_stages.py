@@ -35,7 +35,7 @@ def stage():
 
 
 def test_product_library_has_no_stage_entry_points(prod):
-    assert not hasattr(prod.lib, "CSCST_Analyze") and not hasattr(prod.lib, "CSCST_Filter")
+    assert not hasattr(prod.lib, "CSCST_Analyze") and not hasattr(prod.lib, "CSCST_Filter") and not hasattr(prod.lib, "CSCST_SetPos")
 
 
 @pytest.mark.parametrize("key", sorted(STAGES["analyze"]))
