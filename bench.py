@@ -20,7 +20,8 @@ N > 1  configs[3]: the archiver's `-p8` split of the same file (csarc.cpp:532-54
 
 One JSON line on rank 0: the contract fields + `roofline` (dominant kernel k_encode_runs* against the 8 TB/s HBM peak,
 algorithmic bytes per SURVEY.md section 8d) + `cpu_baseline` (the reference built as oracle/_ref -- or the oracle port --
-timed on this box's host cores over a bounded sample; N = 1 only).
+timed on this box's host cores over a bounded sample: one thread for the single stream, the reference's eight worker processes for
+the task splits (rank 0's host, after the timed region, at every N), the reference archiver `csarc_ref -t8` for `--workload tree`).
 """
 import argparse
 import ctypes as C
@@ -476,7 +477,7 @@ def run_single(args, R, lib, src, level, dict_size):
     return line
 
 
-def run_split(args, R, lib, src, level, dict_size, split, steps, warmup):
+def run_split(args, R, lib, src, level, dict_size, split, steps, warmup, with_cpu=True):
     """the archiver's -p<split> tasks of the file, dealt over the ranks; one batch launch per step and rank"""
     torch = R.torch
     from csc_amd import corpus, tasks
@@ -594,12 +595,60 @@ def run_split(args, R, lib, src, level, dict_size, split, steps, warmup):
         ex = [r["bit_exact_vs_reference"] for r in merged.values()]
         line["bit_exact_vs_reference"] = None if any(e is None for e in ex) else bool(all(ex))
         line["cpu_baseline"] = None
+        if with_cpu and not args.no_cpu_baseline:
+            # rank 0's host cores, after the timed region (the other ranks wait at the closing barrier): the reference's worker
+            # threads as processes, min(8, tasks) of them, each over a bounded prefix of its task
+            try:
+                line["cpu_baseline"] = cpu_baseline_split(src, slices, level, dict_size, args.cpu_split_sample_mib << 20)
+            except Exception as e:          # never lose the bench line to the CPU leg
+                line["cpu_baseline"] = {"error": repr(e)[:300]}
         if exchange is not None:
             line["exchange"] = exchange
     for h in hs:
         L.CSCEnc_Encode_Flush(h)
         L.CSCEnc_Destroy(h)
     return line
+
+
+def cpu_baseline_tree(root, spec, level, dict_size, want_bytes=256 << 20):
+    """the many-task line's CPU leg: the REFERENCE archiver (oracle/_ref/csarc_ref = archiver/*.cpp + libcsc/*.cpp, built by
+    oracle/Makefile) with its own eight worker threads (`-t8`, csarc.cpp:200-201) over whole directories of the same tree until
+    >= want_bytes of input.  A -t8 archive's block order depends on thread timing (csarc.cpp:361-398), so it is timed, not hashed."""
+    import shutil
+    import tempfile
+    from csc_amd import treegen
+    exe = os.path.join(ROOT, "oracle", "_ref", "csarc_ref")
+    if not os.path.exists(exe):
+        return {"error": "oracle/_ref/csarc_ref is not built on this box (oracle/Makefile needs /root/reference)"}
+    by_dir = {}
+    for rel, _kind, _seed, size in treegen.files(spec):
+        by_dir.setdefault(os.path.dirname(rel), []).append(size)
+    dirs, tot, nfiles = [], 0, 0
+    for d in sorted(by_dir):
+        dirs.append(d); tot += sum(by_dir[d]); nfiles += len(by_dir[d])
+        if tot >= want_bytes:
+            break
+    hi = host_info()
+    threads = min(8, hi["usable_cores"])
+    out_dir = tempfile.mkdtemp(prefix="csc_cpu_tree_")
+    try:
+        arc = os.path.join(out_dir, "cpu.csa")
+        t0 = time.perf_counter()
+        p = subprocess.run([exe, "a", "-r", f"-m{level}", f"-d{dict_size >> 20}m", f"-t{threads}", arc] + dirs, cwd=root,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        dt = time.perf_counter() - t0
+        if p.returncode != 0 or not os.path.exists(arc):
+            return {"error": f"csarc_ref failed rc={p.returncode}: {p.stderr[-200:]}"}
+        asize = os.path.getsize(arc)
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+    out = {"value": round(tot / 1e6 / dt, 3), "unit": "MB/s", "cores": threads, "kind": "reference",
+           "sample": f"csarc_ref a -r -m{level} -d{dict_size >> 20}m -t{threads} over {len(dirs)} of the tree's {len(by_dir)} directories ({nfiles} files, {tot} bytes): "
+                     f"the reference archiver itself (oracle/_ref, reference sources, g++ -O4) with its own worker threads, files from the page cache; "
+                     f"timed, not hashed (-t{threads} block order depends on thread timing)",
+           "seconds": round(dt, 2), "ratio": round(asize / max(1, tot), 4)}
+    out.update(hi)
+    return out
 
 
 def run_tree(args, R, spec):
@@ -668,6 +717,11 @@ def run_tree(args, R, spec):
                          "traffic": None, "note": "whole job incl. host I/O: algorithmic bytes of the LZ pass / wall-clock against N x 8 TB/s; kernels: k_encode_runs_multi* (one workgroup per task stream)"},
             "cpu_baseline": None,
         }
+        if not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline_tree(root, spec, level, dict_size)
+            except Exception as e:          # never lose the bench line to the CPU leg
+                line["cpu_baseline"] = {"error": repr(e)[:300]}
         line["last_step_stats_rank0"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()}
         if gold:
             line["cpu_reference_seconds_recorded"] = gold.get("reference_seconds")
@@ -688,7 +742,9 @@ def main():
     ap.add_argument("--config", default="enwik9", choices=sorted(CONFIGS), help="which BASELINE.json workload (N = 1): enwik9 -m3 -d64m (headline), silesia -m5 -d256m, mix5 -m2 -d1024m")
     ap.add_argument("--level", type=int, default=None)
     ap.add_argument("--dict", default=None)
-    ap.add_argument("--split", type=int, default=0, help="task split: 0 = one stream at N = 1, -p8 at N > 1; S > 0 = the -p<S> tasks of the file at any N")
+    ap.add_argument("--split", type=int, default=0, help="task split: 0 = one stream at N = 1 (curve 'single_stream'), -p8 at N > 1 (curve 'p8'); S > 0 = the -p<S> tasks of the "
+                    "file at any N.  The N = 1 point of the p8 curve -- what a scaling sweep over --gpus 2/4/8 must be compared with -- is `--gpus 1 --split 8` "
+                    "(also reported as `p8_on_one_gpu` in the default N = 1 line), NOT the default single-stream line")
     ap.add_argument("--steady-steps", type=int, default=3, help="N = 1 single stream: also time this many chunks after the window has filled (0 = skip)")
     ap.add_argument("--cpu-sample-mib", type=int, default=48)
     ap.add_argument("--cpu-split-sample-mib", type=int, default=24, help="-p8 line's CPU leg: bytes of each task every reference worker process encodes")
@@ -731,7 +787,7 @@ def main():
         if args.config == "enwik9" and args.level is None:
             if args.p8_steps > 0:
                 # the point N = 1 of the -p8 curve (what --gpus 2/4/8 run), as an extra field: `value` stays configs[1]
-                p8 = run_split(args, R, lib, src, level, dict_size, 8, args.p8_steps, 1)
+                p8 = run_split(args, R, lib, src, level, dict_size, 8, args.p8_steps, 1, with_cpu=False)
                 line["p8_on_one_gpu"] = {k: p8[k] for k in ("value", "unit", "ratio", "ms_per_step", "steps", "warmup", "roofline", "bit_exact_vs_reference", "tasks_per_rank")}
                 line["p8_on_one_gpu"]["what"] = p8["config"]["workload"]
                 line["p8_on_one_gpu"]["curve"] = "p8"

@@ -244,6 +244,7 @@ constexpr uint32_t ERR_QUEUE_STALL = 0x40200000u;
 DEV uint32_t q_wait_room(Sc &c, uint32_t need)
 {
     uint32_t used, spins = 0;
+    if (__builtin_expect(c.error != 0, 0)) return 0;      // already gave up once: do not spin for every later entry (the caller ends the kernel at its next check)
     while ((used = c.q_head - UNI(*(volatile __attribute__((address_space(3))) uint32_t *)&c.Q->tail)) > kCoderQ - need) {
         __builtin_amdgcn_s_sleep(2);
         if (++spins > (1u << 24)) { if (!c.error) c.error = ERR_QUEUE_STALL | (used & 0xFFFFu); return 0; }
@@ -725,6 +726,15 @@ DEV void compress_rle(Sc &c, const gu8 *src, uint32_t size)
 #include "csc_kernels_lz.inc"
 #include "csc_kernels_dp2.inc"
 #include "csc_kernels_dp3.inc"
+#if CSCMI_TU != 1
+#include "csc_kernels_bt.inc"
+#else
+DEV bool bt_ok(const Sc &, uint32_t) { return false; }
+DEV void lz_compress_advanced_bt(Sc &, uint32_t) {}
+DEV void bt_init(Sc &) {}
+DEV void bt_inserter(Sc &) {}
+DEV void bt_quit(Sc &) {}
+#endif
 #if CSCMI_TU != 2
 #include "csc_kernels_dp4.inc"
 #else

@@ -37,8 +37,9 @@ typedef struct {
 static struct {
     BtRec rec[BT_R];
     uint32_t sb0, pos0, btpos0, size, head;
-    int la;
-    unsigned long long n_batches, n_events, n_undo_pos, n_fallback_sb, n_pipe_sb, n_samehash, n_extend, n_rounds, n_steps, n_find, n_shadow;
+    int la, pipe;
+    unsigned long long n_batches, n_events, n_undo_pos, n_fallback_sb, n_pipe_sb, n_samehash, n_extend, n_rounds, n_steps, n_find, n_shadow, n_blocked;
+    unsigned long long h_rounds[12], h_chain[12], h_steps[12], n_chainsteps;
 } B;
 
 static void btm_die(const char *what) { fprintf(stderr, "bt_model: %s\n", what); abort(); }
@@ -121,17 +122,30 @@ static void btm_batch(OrcEnc *e, uint32_t i0, uint32_t n)
         const uint32_t btp = B.btpos0 + i0 + k;
         dist[k] = R->dhead; l[k] = btp * 2; r[k] = btp * 2 + 1; lold[k] = rold[k] = 0; lenl[k] = lenr[k] = 0; cyc[k] = 0; runmax[k] = 1;
         R->n = 0; R->un = 0; lsh[k] = rsh[k] = -1;
-        waiting[k] = prevlane[k] >= 0;
+        waiting[k] = !B.pipe && prevlane[k] >= 0;
         active[k] = !waiting[k];
     }
+    {   /* statistics: longest same-hash chain of the batch */
+        uint32_t depth[64], mx = 0;
+        for (uint32_t k = 0; k < n; k++) { depth[k] = prevlane[k] >= 0 ? depth[prevlane[k]] + 1 : 0; if (depth[k] > mx) mx = depth[k]; }
+        uint32_t b = 0; while ((1u << b) <= mx && b < 11) b++;
+        B.h_chain[b]++;
+    }
+    uint32_t rounds_here = 0;
     for (;;) {
         int any = 0;
         for (uint32_t k = 0; k < n; k++) if (active[k] || waiting[k]) any = 1;
         if (!any) break;
-        B.n_rounds++;
+        B.n_rounds++; rounds_here++;
         /* a waiting lane starts once the previous lane of its hash is done */
         for (uint32_t k = 0; k < n; k++)
             if (waiting[k] && !active[prevlane[k]] && !waiting[prevlane[k]]) { waiting[k] = 0; active[k] = 2; }   /* 2: starts next round */
+        /* PIPELINED CHAINS.  A lane does not wait for the earlier lanes of its hash to finish: a descent rewrites the tree top-down and
+         * only ever stores into its two open slots (l, r); everything above them on its path is final, everything off its path is
+         * untouched.  So a later position of the same tree may follow right behind -- it only must not read a node one of whose two
+         * child slots is an open slot of an unfinished earlier position of its hash (snapshot taken when the round starts). */
+        uint32_t hl2[64], hr2[64]; int unf[64];
+        for (uint32_t k = 0; k < n; k++) { hl2[k] = l[k]; hr2[k] = r[k]; unf[k] = active[k] != 0; }
         for (uint32_t k = 0; k < n; k++) {
             if (active[k] == 2) { active[k] = 1; continue; }
             if (!active[k]) continue;
@@ -149,6 +163,22 @@ static void btm_batch(OrcEnc *e, uint32_t i0, uint32_t n)
             const uint32_t climit = UMIN(limit, e->wnd_size - cp);
             if (clen >= climit) { BT_STORE_L(0); BT_STORE_R(0); active[k] = 0; continue; }
             const uint32_t npos = btp >= dist[k] ? btp - dist[k] : btp + e->bt_size - dist[k];
+            if (B.pipe) {
+                /* which child slot of the node this step needs is known from the window bytes alone: the one it will move to
+                 * (both when the step ends the descent by copying the node's children, :185, :433) */
+                const uint32_t c2 = UMIN(e->good_len, climit);
+                const uint32_t f = btm_prefix_from(e->wnd + wpos, e->wnd + cp, clen, c2);
+                const int both = f >= e->good_len || B.pipe == 1;
+                const int ends0 = f > clen && f < e->good_len && f >= c2;       /* ends with zero children: needs neither */
+                const uint32_t need = e->wnd[cp + f] < e->wnd[wpos + f] ? npos * 2 + 1 : npos * 2;
+                int blocked = 0;
+                for (uint32_t j = 0; j < k; j++) {
+                    if (!unf[j] || hb[j] != hb[k]) continue;
+                    if (both) { if (hl2[j] >> 1 == npos || hr2[j] >> 1 == npos) blocked = 1; }
+                    else if (!ends0 && (hl2[j] == need || hr2[j] == need)) blocked = 1;
+                }
+                if (blocked) { B.n_blocked++; continue; }
+            }
             const uint32_t rel = npos - (B.btpos0 + i0);
             const int shadowed = rel < n && rel > k;
             if (shadowed) B.n_shadow++;
@@ -179,6 +209,8 @@ static void btm_batch(OrcEnc *e, uint32_t i0, uint32_t n)
             cyc[k]++;
         }
     }
+    { uint32_t b = 0; while ((1u << b) <= rounds_here && b < 11) b++; B.h_rounds[b]++; }
+    for (uint32_t k = 0; k < n; k++) { uint32_t st = cyc[k], b = 0; while ((1u << b) <= st && b < 11) b++; B.h_steps[b]++; if (prevlane[k] >= 0) B.n_chainsteps += st; }
 }
 
 /* take back the inserts of positions [a, head), newest first */
@@ -411,10 +443,15 @@ __attribute__((destructor)) static void btm_stats(void)
     if (!getenv("BTM_STATS")) return;
     fprintf(stderr, "bt_model: sub-blocks pipe %llu fallback %llu, batches %llu, rounds %llu, steps %llu, finds %llu, same-hash lanes %llu, long-match events %llu, positions undone %llu, extensions %llu, shadowed steps %llu\n",
             B.n_pipe_sb, B.n_fallback_sb, B.n_batches, B.n_rounds, B.n_steps, B.n_find, B.n_samehash, B.n_events, B.n_undo_pos, B.n_extend, B.n_shadow);
+    fprintf(stderr, "bt_model: histograms (bucket b: value < 2^b): rounds/batch"); for (int i = 0; i < 12; i++) fprintf(stderr, " %llu", B.h_rounds[i]);
+    fprintf(stderr, " | longest chain/batch"); for (int i = 0; i < 12; i++) fprintf(stderr, " %llu", B.h_chain[i]);
+    fprintf(stderr, " | steps/lane"); for (int i = 0; i < 12; i++) fprintf(stderr, " %llu", B.h_steps[i]);
+    fprintf(stderr, " | steps of chained lanes %llu | blocked lane-rounds %llu\n", B.n_chainsteps, B.n_blocked);
 }
 __attribute__((constructor)) static void btm_install(void)
 {
     const char *s;
     B.la = (s = getenv("BTM_LA")) ? atoi(s) : 64;
+    B.pipe = (s = getenv("BTM_PIPE")) ? atoi(s) : 1;
     orc_adv_hook = btm_adv;
 }

@@ -346,13 +346,16 @@ def test_bench_multi_rank_path_two_processes(tmp_path):
     Two ranks share the one GPU of this box over gloo (CSC_BENCH_BACKEND, tests only; the driver's runs use RCCL)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(CSC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--cpu-split-sample-mib", "2"],
                          cwd=tmp_path, env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1, out.stdout[-2000:]
     d = json.loads(line[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["cpu_baseline"] is None
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    # the CPU leg is on every line the driver can ask for: the reference's worker processes on rank 0's host cores
+    cb = d["cpu_baseline"]
+    assert cb and "error" not in cb and cb["value"] > 0 and cb["unit"] == "MB/s" and 1 <= cb["cores"] <= 8 and cb["kind"] in ("reference", "port")
     assert d["tasks_per_rank"] == [4, 4] and len(d["tasks"]) == 8
     assert d["bit_exact_vs_reference"] is True, d["tasks"]
     assert {t["rank"] for t in d["tasks"]} == {0, 1} and all(t["chunks"] == 2 for t in d["tasks"])
@@ -373,3 +376,5 @@ def test_bench_tree_workload_small_archive_equals_reference(tmp_path):
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["bit_exact_vs_reference"] is True and line["curve"] == "tree_small" and line["config"]["tasks"] == 128
     assert line["value"] > 0 and line["scaling"] == "strong"
+    cb = line["cpu_baseline"]       # the reference archiver itself, timed on this box (oracle/_ref/csarc_ref -t8)
+    assert cb and (("error" in cb and "csarc_ref" in cb["error"]) or (cb["value"] > 0 and cb["kind"] == "reference" and cb["cores"] >= 1))

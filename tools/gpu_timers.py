@@ -35,7 +35,10 @@ names = ["fm:hash+gather", "fm:slots+extend", "fm:replay+insert", "pricing", "dp
 if PAIR:
     names = ["M pre:tables", "M pre:wait labels", "M pre:reps+lit", "M wait decision", "M crit", "M post:pricing", "M post:relax", "M way out",
              "H pre:tables", "H pre:wait labels", "H pre:reps+lit", "H wait decision", "H crit", "H post:pricing", "H post:relax", "-"]
-tot = sum(tm)
+if level == 5 and not PAIR:      # the inserter form (csc_kernels_bt.inc): parser wavefront 0-7, inserter wavefront 8-11
+    names = ["P wait for the record", "P record + rep compare", "P acceptance", "P pricing", "P dp:statefix", "P dp:litprice+relax", "P dp:exit(backward+encode)", "-",
+             "I gather + same-key", "I HT2/HT3/far lengths", "I descents", "I skip events (undo + replay)", "-", "-", "-", "-"]
+tot = sum(tm[:8]) if level == 5 and not PAIR else sum(tm)
 print(f"level {level}: {len(data)/1e6/dt:.3f} MB/s, kernel {st.encode_kernel_ms:.0f} ms, find_match {st.find}, slide {st.slide}, lit {st.lit}, match {st.match}, bt {st.bt} = redo_y {st.bt >> 16} redo_x {st.bt & 0xFFFF}")
 for n, v in zip(names, tm):
     if v: print(f"  {n:34s} {v/1e6:10.1f} Mcyc  {100*v/tot:5.1f}%   {v/max(1,st.find):8.0f} cyc/find_match")
