@@ -546,6 +546,8 @@ CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *outstream, ISzA
         if ((e->parser & 4) && props->lz_mode == 3 && props->hash_width <= 2 && props->good_len >= 2 && props->good_len <= 16) e->parser |= 8;
         // level-5 geometry -- binary tree, no bucket, advanced parser: the inserter form (csc_kernels_bt.inc)
         if (bt && !ht && props->lz_mode == 3 && props->bt_cyc <= 32) e->parser |= 16;
+        // lazy / greedy parser over a bucket of up to eight (levels 1, 2): the inserter form (csc_kernels_hp.inc)
+        if ((e->parser & 4) && props->lz_mode != 3 && props->hash_width <= 8) e->parser |= 32;
     }
     bool ok = hipGetDevice(&e->device) == hipSuccess;
     // each process/thread may sit on another device: the constant tables are per device
@@ -702,7 +704,7 @@ int CSCMI_EncodeDeviceChunkBatch(int n, CSCEncHandle *hs, const void *const *dev
         }
         for (int i = 0; i < n; i++) all_done = all_done && (!sizes[i] || state[i] == 2);
         // this round's launches: the waiting streams' runs so far, or -- last round -- everybody's remaining runs
-        for (int parser = 2; parser <= 31; parser++) {
+        for (int parser = 2; parser <= 63; parser++) {
             if ((parser & 3) < 2) continue;
             uint32_t m = 0;
             EncState **st = (EncState **)h_batch;

@@ -728,7 +728,13 @@ DEV void compress_rle(Sc &c, const gu8 *src, uint32_t size)
 #include "csc_kernels_dp3.inc"
 #if CSCMI_TU != 1
 #include "csc_kernels_bt.inc"
+#include "csc_kernels_hp.inc"
 #else
+DEV bool hp_ok(const Sc &) { return false; }
+DEV void lz_compress_normal_hp(Sc &, uint32_t, bool) {}
+DEV void hp_init(Sc &) {}
+DEV void hp_inserter(Sc &) {}
+DEV void hp_quit(Sc &) {}
 DEV bool bt_ok(const Sc &, uint32_t) { return false; }
 DEV void lz_compress_advanced_bt(Sc &, uint32_t) {}
 DEV void bt_init(Sc &) {}

@@ -1086,6 +1086,8 @@ static void lz_compress_advanced(OrcEnc *e, uint32_t size)
 /* Test hook (NULL in liborc.so): tests/model/m3_model.c includes this file and points it at its own arrangement of
  * compress_advanced -- the one the HIP kernels use -- to prove that arrangement equal to the one above. */
 static void (*orc_adv_hook)(OrcEnc *e, uint32_t size);
+/* the same for compress_normal (tests/model/hp_model.c: the lazy levels' arrangement) */
+static void (*orc_norm_hook)(OrcEnc *e, uint32_t size, int lazy);
 
 /* LZ::EncodeNormal, csc_lz.cpp:61-100 */
 static void lz_encode_normal(OrcEnc *e, const uint8_t *src, uint32_t size, uint32_t lz_mode)
@@ -1094,8 +1096,7 @@ static void lz_encode_normal(OrcEnc *e, const uint8_t *src, uint32_t size, uint3
         uint32_t cur = UMIN(e->wnd_size - e->wnd_curpos, size - i);
         cur = UMIN(cur, MIN_BLOCK);
         memcpy(e->wnd + e->wnd_curpos, src + i, cur);
-        if (lz_mode == 1) lz_compress_normal(e, cur, 0);
-        else if (lz_mode == 2) lz_compress_normal(e, cur, 1);
+        if (lz_mode == 1 || lz_mode == 2) { if (orc_norm_hook) orc_norm_hook(e, cur, lz_mode == 2); else lz_compress_normal(e, cur, lz_mode == 2); }
         else if (lz_mode == 3) { if (orc_adv_hook) orc_adv_hook(e, cur); else lz_compress_advanced(e, cur); }
         else if (lz_mode == 5) {
             mf_set_arg(e, 1, 1, 0, e->lz_good_len);

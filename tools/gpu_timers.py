@@ -38,7 +38,10 @@ if PAIR:
 if level == 5 and not PAIR:      # the inserter form (csc_kernels_bt.inc): parser wavefront 0-7, inserter wavefront 8-11
     names = ["P wait for the record", "P record + rep compare", "P acceptance", "P pricing", "P dp:statefix", "P dp:litprice+relax", "P dp:exit(backward+encode)", "-",
              "I gather + same-key", "I HT2/HT3/far lengths", "I descents", "I skip events (undo + replay)", "-", "-", "-", "-"]
-tot = sum(tm[:8]) if level == 5 and not PAIR else sum(tm)
+if level in (1, 2) and not PAIR:   # the inserter form of the lazy levels (csc_kernels_hp.inc): parser wavefront 0-11, inserter wavefront 12-15
+    names = ["P wait for the record", "P record + rep compare", "P acceptance", "-", "-", "-", "-", "P slide check / event", "dict filter", "window memcpy",
+             "P symbol -> token", "P FindMatch pick", "I gather + same-key + stores", "I lengths + record", "-", "I events (undo / exact slide)"]
+tot = sum(tm[:8]) if level == 5 and not PAIR else sum(tm[:12]) if level in (1, 2) and not PAIR else sum(tm)
 print(f"level {level}: {len(data)/1e6/dt:.3f} MB/s, kernel {st.encode_kernel_ms:.0f} ms, find_match {st.find}, slide {st.slide}, lit {st.lit}, match {st.match}, bt {st.bt} = redo_y {st.bt >> 16} redo_x {st.bt & 0xFFFF}")
 for n, v in zip(names, tm):
     if v: print(f"  {n:34s} {v/1e6:10.1f} Mcyc  {100*v/tot:5.1f}%   {v/max(1,st.find):8.0f} cyc/find_match")
