@@ -62,7 +62,7 @@ print("MODEL_OK", n)
 
 
 @pytest.mark.parametrize("knobs", [
-    {"HPM_LA": 64},      # the kernel's look-ahead: 64 positions + one batch
+    {"HPM_LA": 128},     # the kernel's look-ahead: 128 positions + one batch
     {"HPM_LA": 0},       # inserter as close to the parser as batches allow
     {"HPM_LA": 190},     # far ahead: long undo ranges
 ])
