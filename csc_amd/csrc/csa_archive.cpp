@@ -40,7 +40,7 @@ constexpr uint64_t kHeaderSize = 24;                 // csarc.cpp:561
 constexpr uint64_t kBlockCap = 1048576;              // csa_io.h:158
 constexpr uint32_t kAdlerBase = 65521;
 constexpr uint32_t kAdlerPiece = 16384;              // bytes per k_adler_pieces workgroup
-constexpr int kMaxStreams = 1024;
+constexpr int kMaxStreams = 2048;        // = kMaxBatch of csc_host.cpp: one launch takes them all; the GPU starts the next workgroup where one ends
 constexpr int kStageBufs = 8;
 constexpr uint32_t kMaxFrags = CSA_MAX_FRAGMENTS;
 const char *const kDummyName = "****";               // csa_common.h:79

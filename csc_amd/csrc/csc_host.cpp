@@ -10,6 +10,7 @@
 // in HIP kernels on state that lives in HBM.  There is NO CPU fallback: without a HIP device
 // CSCEnc_Create fails loudly and returns NULL.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <math.h>
 #include <stdio.h>
@@ -243,7 +244,7 @@ struct EncInstance {
 };
 // argument arrays of the multi-stream launch ([4 * kMaxBatch] pointer-sized words: states, run lists, run
 // counts, reset flags), one set per calling thread and device, kept for the life of the thread
-struct BatchArgs { int device = -1; void **d = nullptr; void **h = nullptr; };
+struct BatchArgs { int device = -1; void **d = nullptr; void **h = nullptr; void **d2 = nullptr; void **h2 = nullptr; hipStream_t side = nullptr; };
 thread_local BatchArgs t_batch;
 constexpr int kMaxBatch = 2048;
 
@@ -676,23 +677,42 @@ int CSCMI_EncodeDeviceChunkBatch(int n, CSCEncHandle *hs, const void *const *dev
     if (t_batch.device != lead->device) {
         if (t_batch.d) (void)hipFree(t_batch.d);
         if (t_batch.h) (void)hipHostFree(t_batch.h);
+        if (t_batch.d2) (void)hipFree(t_batch.d2);
+        if (t_batch.h2) (void)hipHostFree(t_batch.h2);
+        if (t_batch.side) (void)hipStreamDestroy(t_batch.side);
         t_batch = BatchArgs();
         HIPCHK(hipMalloc((void **)&t_batch.d, sizeof(void *) * 4 * kMaxBatch));
         HIPCHK(hipHostMalloc((void **)&t_batch.h, sizeof(void *) * 4 * kMaxBatch, hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&t_batch.d2, sizeof(void *) * 4 * kMaxBatch));
+        HIPCHK(hipHostMalloc((void **)&t_batch.h2, sizeof(void *) * 4 * kMaxBatch, hipHostMallocDefault));
+        HIPCHK(hipStreamCreateWithFlags(&t_batch.side, hipStreamNonBlocking));
         t_batch.device = lead->device;
     }
     void **const d_batch = t_batch.d, **const h_batch = t_batch.h;
     int rc = 0;
+    static const bool trace = getenv("CSCMI_BATCH_TRACE") != nullptr;      // development: one line per round on stderr
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t_begin = tnow();
     for (int i = 0; i < n && !rc; i++) rc = sizes[i] ? chunk_begin((EncInstance *)hs[i], device_ptrs[i], sizes[i], true) : 0;
+    const auto t_cb = tnow();
     for (int i = 0; i < n && !rc; i++) rc = sizes[i] ? seg_begin((EncInstance *)hs[i]) : 0;
     if (rc) return rc;
+    if (trace) fprintf(stderr, "batch trace: %d streams: chunk_begin %.1f ms, seg_begin %.1f ms\n", n, tms(t_begin, t_cb), tms(t_cb, tnow()));
+    double ms_dup = 0;
     // Rounds: every stream's run segmentation goes on until it needs an IsDuplicateBlock verdict (csc_encoder_main.cpp:123-126: the
     // runs so far must have been encoded first) or is complete.  The streams that wait for a verdict have their runs so far
     // launched TOGETHER (one launch per parser flavour, one workgroup per stream), then their duplicate checks, one wait for all;
     // the last round launches what is left of every stream.  (Stream by stream -- as CSCEnc_Encode does it for one handle -- a
     // batch of streams with high-entropy / delta blocks ran one workgroup at a time.)
     std::vector<uint8_t> state(n, 0);                // 0 walking, 1 waits for a verdict, 2 run list complete
+    int round = 0;
+    uint32_t side_used = 0;
+    bool side_any = false;
     for (;;) {
+        const auto t_round = std::chrono::steady_clock::now();
+        uint32_t tr_streams = 0, tr_wait = 0;
+        round++;
         bool any_wait = false, all_done = true;
         for (int i = 0; i < n; i++) {
             if (!sizes[i] || state[i] == 2) continue;
@@ -703,40 +723,66 @@ int CSCMI_EncodeDeviceChunkBatch(int n, CSCEncHandle *hs, const void *const *dev
             any_wait = any_wait || r == 1;
         }
         for (int i = 0; i < n; i++) all_done = all_done && (!sizes[i] || state[i] == 2);
-        // this round's launches: the waiting streams' runs so far, or -- last round -- everybody's remaining runs
-        for (int parser = 2; parser <= 63; parser++) {
-            if ((parser & 3) < 2) continue;
-            uint32_t m = 0;
-            EncState **st = (EncState **)h_batch;
-            const RunDesc **rl = (const RunDesc **)(h_batch + kMaxBatch);
-            uint32_t *cnt = (uint32_t *)(h_batch + 2 * kMaxBatch);
-            uint32_t *rst = (uint32_t *)(h_batch + 3 * kMaxBatch);
-            for (int i = 0; i < n; i++) {
-                EncInstance *e = (EncInstance *)hs[i];
-                if (!sizes[i] || e->parser != parser) continue;
-                if (!(all_done || state[i] == 1)) continue;
-                EncInstance::Seg &g = e->seg;
-                if (g.launched == g.nruns) continue;
-                HIPCHK(hipMemcpyAsync(e->d_runs + g.launched, e->h_runs + g.launched, sizeof(RunDesc) * (g.nruns - g.launched),
-                                      hipMemcpyHostToDevice, lead->stream));
-                st[m] = e->d_state; rl[m] = e->d_runs + g.launched; cnt[m] = g.nruns - g.launched; rst[m] = g.first_launch ? 1u : 0u;
-                g.launched = g.nruns; g.first_launch = false;
-                m++;
+        // this round's launches.  A stream whose run list is COMPLETE needs nothing from the host any more: its remaining runs go out
+        // at once on a stream of their own (`side`) and run while the streams that wait for verdicts go through their rounds (the
+        // reference's workers do not wait for each other either, csarc.cpp:361-398); the waiting streams' runs so far go out on the
+        // lead's stream, which every round waits for.
+        for (int pass = 0; pass < 2; pass++) {                    // 0: complete streams -> side, 1: waiting streams -> lead's stream
+            for (int parser = 2; parser <= 63; parser++) {
+                if ((parser & 3) < 2) continue;
+                hipStream_t lst = pass == 0 ? t_batch.side : lead->stream;
+                void **hb = pass == 0 ? t_batch.h2 + side_used : h_batch, **db = pass == 0 ? t_batch.d2 + side_used : d_batch;
+                uint32_t m = 0;
+                EncState **st = (EncState **)hb;
+                const RunDesc **rl = (const RunDesc **)(hb + kMaxBatch);
+                uint32_t *cnt = (uint32_t *)(hb + 2 * kMaxBatch);
+                uint32_t *rst = (uint32_t *)(hb + 3 * kMaxBatch);
+                for (int i = 0; i < n; i++) {
+                    EncInstance *e = (EncInstance *)hs[i];
+                    if (!sizes[i] || e->parser != parser) continue;
+                    if (state[i] != (pass == 0 ? 2 : 1)) continue;
+                    EncInstance::Seg &g = e->seg;
+                    if (g.launched == g.nruns) continue;
+                    HIPCHK(hipMemcpyAsync(e->d_runs + g.launched, e->h_runs + g.launched, sizeof(RunDesc) * (g.nruns - g.launched),
+                                          hipMemcpyHostToDevice, lst));
+                    st[m] = e->d_state; rl[m] = e->d_runs + g.launched; cnt[m] = g.nruns - g.launched; rst[m] = g.first_launch ? 1u : 0u;
+                    g.launched = g.nruns; g.first_launch = false;
+                    m++;
+                }
+                if (!m) continue;
+                tr_streams += m;
+                if (pass == 0) {
+                    // (the four arrays of this launch start at entry side_used of the second table; nothing overwrites them before the end)
+                    for (int q = 0; q < 4; q++)
+                        HIPCHK(hipMemcpyAsync(db + q * kMaxBatch, hb + q * kMaxBatch, sizeof(void *) * m, hipMemcpyHostToDevice, lst));
+                    if (!side_any) HIPCHK(hipEventRecord(lead->ev[1][0], lst));
+                    launch_encode_runs_multi(parser, m, (EncState *const *)db, (const RunDesc *const *)(db + kMaxBatch),
+                                             (const uint32_t *)(db + 2 * kMaxBatch), (const uint32_t *)(db + 3 * kMaxBatch), lst);
+                    HIPCHK(hipGetLastError());
+                    side_used += m; side_any = true;
+                    lead->stats.encode_launches++;
+                    continue;
+                }
+                HIPCHK(hipMemcpyAsync(d_batch, h_batch, sizeof(void *) * 4 * kMaxBatch, hipMemcpyHostToDevice, lead->stream));
+                HIPCHK(hipEventRecord(lead->ev[0][0], lead->stream));
+                launch_encode_runs_multi(parser, m, (EncState *const *)d_batch, (const RunDesc *const *)(d_batch + kMaxBatch),
+                                         (const uint32_t *)(d_batch + 2 * kMaxBatch), (const uint32_t *)(d_batch + 3 * kMaxBatch), lead->stream);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipEventRecord(lead->ev[0][1], lead->stream));
+                HIPCHK(hipStreamSynchronize(lead->stream));          // (the pointer tables are reused by the next flavour / round)
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, lead->ev[0][0], lead->ev[0][1]) == hipSuccess) lead->stats.encode_kernel_ms += ms;
+                lead->stats.encode_launches++;
             }
-            if (!m) continue;
-            HIPCHK(hipMemcpyAsync(d_batch, h_batch, sizeof(void *) * 4 * kMaxBatch, hipMemcpyHostToDevice, lead->stream));
-            HIPCHK(hipEventRecord(lead->ev[0][0], lead->stream));
-            launch_encode_runs_multi(parser, m, (EncState *const *)d_batch, (const RunDesc *const *)(d_batch + kMaxBatch),
-                                     (const uint32_t *)(d_batch + 2 * kMaxBatch), (const uint32_t *)(d_batch + 3 * kMaxBatch), lead->stream);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(lead->ev[0][1], lead->stream));
-            HIPCHK(hipStreamSynchronize(lead->stream));          // (the pointer tables are reused by the next flavour / round)
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, lead->ev[0][0], lead->ev[0][1]) == hipSuccess) lead->stats.encode_kernel_ms += ms;
-            lead->stats.encode_launches++;
+        }
+        if (trace) {
+            for (int i = 0; i < n; i++) tr_wait += sizes[i] && state[i] == 1;
+            fprintf(stderr, "batch trace: round %d: %u streams launched, %u wait for a verdict, %.1f ms%s\n", round, tr_streams, tr_wait,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_round).count(), all_done ? " (last)" : "");
         }
         if (all_done) break;
         // the verdicts the waiting streams asked for, all in flight before the one wait
+        const auto t_dup = tnow();
         for (int i = 0; i < n; i++) {
             if (!sizes[i] || state[i] != 1) continue;
             EncInstance *e = (EncInstance *)hs[i];
@@ -752,7 +798,15 @@ int CSCMI_EncodeDeviceChunkBatch(int n, CSCEncHandle *hs, const void *const *dev
             g.dup_from = g.need_blk; g.dup_to = g.need_blk + g.need_cnt;
             state[i] = 0;
         }
+        ms_dup += tms(t_dup, tnow());
     }
+    if (side_any) {
+        HIPCHK(hipEventRecord(lead->ev[1][1], t_batch.side));
+        HIPCHK(hipStreamSynchronize(t_batch.side));
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, lead->ev[1][0], lead->ev[1][1]) == hipSuccess) lead->stats.encode_kernel_ms += ms;
+    }
+    const auto t_drain = tnow();
     for (int i = 0; i < n; i++) {
         if (!sizes[i]) continue;
         EncInstance *e = (EncInstance *)hs[i];
@@ -764,6 +818,7 @@ int CSCMI_EncodeDeviceChunkBatch(int n, CSCEncHandle *hs, const void *const *dev
         int r = drain_arena((EncInstance *)hs[i], 0);
         if (r && !rc) rc = r;
     }
+    if (trace) fprintf(stderr, "batch trace: %d rounds, duplicate checks %.1f ms, drain %.1f ms, whole call %.1f ms\n", round, ms_dup, tms(t_drain, tnow()), tms(t_begin, tnow()));
     return rc;
 }
 

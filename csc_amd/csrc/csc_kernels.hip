@@ -739,6 +739,7 @@ DEV bool bt_ok(const Sc &, uint32_t) { return false; }
 DEV void lz_compress_advanced_bt(Sc &, uint32_t) {}
 DEV void bt_init(Sc &) {}
 DEV void bt_inserter(Sc &) {}
+DEV void bt_post(Sc &) {}
 DEV void bt_quit(Sc &) {}
 #endif
 #if CSCMI_TU != 2
