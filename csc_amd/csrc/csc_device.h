@@ -43,6 +43,7 @@ enum : uint32_t {
 };
 
 enum : uint32_t { ERR_NONE = 0, ERR_ARENA_FULL = 1, ERR_BAD_TYPE = 2, ERR_PAIR_STALL = 3 };
+constexpr uint32_t kSelfSegment = 0x80000000u;   // k_encode_runs*: nruns = kSelfSegment | chunk bytes -- the kernel walks the chunk's blocks itself (enc_compress_chunk)
 
 // one finished coder block in the output arena: 16-byte header, payload padded to 16
 struct ArenaRec {
@@ -82,7 +83,7 @@ struct EncState {
     uint32_t wnd_size, vld_rge, bsize, raw_blocksize;
     uint32_t ht_bits, ht_width, bt_bits, bt_size;
     uint32_t lz_mode, lz_good_len, lz_bt_cyc, lz_ht_cyc;
-    uint32_t arena_cap, pad0;
+    uint32_t arena_cap, filt_flags;   // filt_flags: bit 0 DLTFilter, 1 TXTFilter, 2 EXEFilter (csc_common.h:52-56)
     uint64_t mf_size;          // words in mfbuf (ht2|ht3|ht6|bt_head|bt_nodes)
 
     // ---- HBM arrays ----

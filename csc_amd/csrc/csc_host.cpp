@@ -322,10 +322,31 @@ int drain_arena(EncInstance *e, int ev_used)
 //   chunk_segment wait for the verdicts, build the run list (may launch + wait for duplicate-block
 //                 checks), then either launch the remaining runs or leave them pending
 //   chunk_finish  read the coder blocks back and call the user's Write
-int chunk_begin(EncInstance *e, const void *src, size_t size, bool on_device)
+// The chunk's blocks are walked by the encode kernel itself (enc_compress_chunk, csc_kernels_blocks.inc): typing, duplicate-block
+// checks and run formation need no host round trip.  CSCMI_HOST_SEGMENT=1 (diagnostics) keeps the walk on the host as rounds
+// 1-3 had it: the run list is built here, every IsDuplicateBlock verdict costs a launch boundary.
+bool host_segment()
+{
+    static const bool v = [] { const char *s = getenv("CSCMI_HOST_SEGMENT"); return s && atoi(s) != 0; }();
+    return v;
+}
+
+int chunk_begin(EncInstance *e, const void *src, size_t size, bool on_device, hipStream_t st = nullptr)
 {
     if (size == 0 || size > e->props.raw_blocksize) return -1;
     HIPCHK(hipSetDevice(e->device));
+    if (!st) st = e->stream;
+    if (!host_segment()) {
+        HIPCHK(hipMemcpyAsync(e->h.inbuf, src, size, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        if ((e->props.DLTFilter + e->props.EXEFilter + e->props.TXTFilter) != 0) {
+            const bool timed = st == e->stream;          // (a batch queues every stream's analyzer on the lead's stream: not timed one by one)
+            if (timed) HIPCHK(hipEventRecord(e->ev_an[0], st));
+            launch_analyze(e->d_state, (uint32_t)size, e->d_entcoef, st);
+            HIPCHK(hipGetLastError());
+            if (timed) HIPCHK(hipEventRecord(e->ev_an[1], st));
+        }
+        return 0;
+    }
     HIPCHK(hipMemcpyAsync(e->h.inbuf, src, size, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
     const uint32_t csize = (uint32_t)size;
     const uint32_t nblk = (csize + kMinBlock - 1) / kMinBlock;
@@ -445,6 +466,20 @@ int encode_chunk(EncInstance *e, const void *src, size_t size, bool on_device)
     if (size == 0) return 0;
     int rc = chunk_begin(e, src, size, on_device);
     if (rc) return rc;
+    if (!host_segment()) {
+        HIPCHK(hipEventRecord(e->ev[0][0], e->stream));
+        launch_encode_runs(e->parser, e->d_state, e->d_runs, kSelfSegment | (uint32_t)size, 1u, e->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(e->ev[0][1], e->stream));
+        e->stats.encode_launches++;
+        e->stats.chunks++;
+        e->stats.input_bytes += size;
+        rc = drain_arena(e, 1);
+        float ms = 0;
+        if ((e->props.DLTFilter + e->props.EXEFilter + e->props.TXTFilter) != 0 && hipEventElapsedTime(&ms, e->ev_an[0], e->ev_an[1]) == hipSuccess)
+            e->stats.analyze_kernel_ms += ms;
+        return rc;
+    }
     rc = chunk_segment(e, size, false);
     if (rc) return rc;
     return drain_arena(e, e->pend_ev);
@@ -571,6 +606,7 @@ CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *outstream, ISzA
     h.mf_size = (uint64_t)kHT2Size + kHT3Size + ((uint64_t)h.ht_width << h.ht_bits);
     if (h.bt_bits) h.mf_size += ((uint64_t)1 << h.bt_bits) + (uint64_t)h.bt_size * 2;
     h.arena_cap = 3 * props->raw_blocksize + kMB;
+    h.filt_flags = (props->DLTFilter ? 1u : 0u) | (props->TXTFilter ? 2u : 0u) | (props->EXEFilter ? 4u : 0u);
 
     // ---- one device slab, zero-filled: memset(wnd_, 0, ..) csc_lz.cpp:50, the tables csc_mf.cpp:73, and the
     // coder buffers, which the reference reads before writing (App. C #1)
@@ -694,6 +730,52 @@ int CSCMI_EncodeDeviceChunkBatch(int n, CSCEncHandle *hs, const void *const *dev
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t_begin = tnow();
+    if (!host_segment()) {
+        // every stream walks its chunk itself: upload + analyzer per stream, then ONE launch per kernel flavour, one workgroup a stream
+        for (int i = 0; i < n && !rc; i++) {
+            if (!sizes[i]) continue;
+            EncInstance *e = (EncInstance *)hs[i];
+            if (e->stats.chunks == 0 && e->stream != lead->stream) HIPCHK(hipStreamSynchronize(e->stream));   // (its state was initialised on its own stream)
+            rc = chunk_begin(e, device_ptrs[i], sizes[i], true, lead->stream);
+        }
+        if (rc) return rc;
+        for (int parser = 2; parser <= 63; parser++) {
+            if ((parser & 3) < 2) continue;
+            uint32_t m = 0;
+            EncState **st = (EncState **)h_batch;
+            const RunDesc **rl = (const RunDesc **)(h_batch + kMaxBatch);
+            uint32_t *cnt = (uint32_t *)(h_batch + 2 * kMaxBatch);
+            uint32_t *rst = (uint32_t *)(h_batch + 3 * kMaxBatch);
+            for (int i = 0; i < n; i++) {
+                EncInstance *e = (EncInstance *)hs[i];
+                if (!sizes[i] || e->parser != parser) continue;
+                st[m] = e->d_state; rl[m] = e->d_runs; cnt[m] = kSelfSegment | (uint32_t)sizes[i]; rst[m] = 1u;
+                m++;
+            }
+            if (!m) continue;
+            HIPCHK(hipMemcpyAsync(d_batch, h_batch, sizeof(void *) * 4 * kMaxBatch, hipMemcpyHostToDevice, lead->stream));
+            HIPCHK(hipEventRecord(lead->ev[0][0], lead->stream));
+            launch_encode_runs_multi(parser, m, (EncState *const *)d_batch, (const RunDesc *const *)(d_batch + kMaxBatch),
+                                     (const uint32_t *)(d_batch + 2 * kMaxBatch), (const uint32_t *)(d_batch + 3 * kMaxBatch), lead->stream);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(lead->ev[0][1], lead->stream));
+            HIPCHK(hipStreamSynchronize(lead->stream));          // (the pointer tables are reused by the next flavour)
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, lead->ev[0][0], lead->ev[0][1]) == hipSuccess) lead->stats.encode_kernel_ms += ms;
+            lead->stats.encode_launches++;
+        }
+        const auto t_dr = tnow();
+        for (int i = 0; i < n; i++) {
+            if (!sizes[i]) continue;
+            EncInstance *e = (EncInstance *)hs[i];
+            e->stats.chunks++;
+            e->stats.input_bytes += sizes[i];
+            int r = drain_arena(e, 0);
+            if (r && !rc) rc = r;
+        }
+        if (trace) fprintf(stderr, "batch trace: %d streams, kernels walk their chunks: launches %.1f ms, drain %.1f ms\n", n, tms(t_begin, t_dr), tms(t_dr, tnow()));
+        return rc;
+    }
     for (int i = 0; i < n && !rc; i++) rc = sizes[i] ? chunk_begin((EncInstance *)hs[i], device_ptrs[i], sizes[i], true) : 0;
     const auto t_cb = tnow();
     for (int i = 0; i < n && !rc; i++) rc = sizes[i] ? seg_begin((EncInstance *)hs[i]) : 0;
