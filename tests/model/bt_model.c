@@ -452,6 +452,6 @@ __attribute__((constructor)) static void btm_install(void)
 {
     const char *s;
     B.la = (s = getenv("BTM_LA")) ? atoi(s) : 64;
-    B.pipe = (s = getenv("BTM_PIPE")) ? atoi(s) : 1;
+    B.pipe = (s = getenv("BTM_PIPE")) ? atoi(s) : 2;   /* 2 = the kernel's rule (only the child slot the step needs), 1 = both child slots, 0 = chains one after the other */
     orc_adv_hook = btm_adv;
 }

@@ -1,6 +1,7 @@
 """CPU tier: tests/model/bt_model.c -- the ARRANGEMENT the HIP kernels give the binary-tree match finder of level 5
 (csc_amd/csrc/csc_kernels_bt.inc: an inserter that runs ahead of the parser, 64 positions per batch with interleaved descents,
-per-position records, an undo log for the long-match skip rule, find_match's acceptance over a record) -- must produce the
+same-hash positions following each other down their tree, shadow copies of reused ring slots, per-position records, an undo log
+for the long-match skip rule, find_match's acceptance over a record) -- must produce the
 oracle's bytes.  The model includes the oracle's encoder and replaces compress_advanced only; both are test infrastructure."""
 import os
 import re
@@ -62,7 +63,7 @@ print("MODEL_OK", n)
 ])
 def test_model_equals_oracle(built, knobs):
     err = run_cases(knobs)
-    line = [l for l in err.splitlines() if l.startswith("bt_model:")]
+    line = [l for l in err.splitlines() if l.startswith("bt_model: sub-blocks")]
     assert line, err[-500:]
     s = line[-1]
     # the paths the kernel's exactness rests on must have been walked
@@ -72,3 +73,6 @@ def test_model_equals_oracle(built, knobs):
     assert int(re.search(r"long-match events (\d+)", s).group(1)) > 100, s        # skip rule: undo + replay
     assert int(re.search(r"positions undone (\d+)", s).group(1)) > 1000, s
     assert int(re.search(r"extensions (\d+)", s).group(1)) > 100, s               # capped lengths extended on demand
+    assert int(re.search(r"shadowed steps (\d+)", s).group(1)) > 50, s           # ring slots of later positions of the batch (custom geometry)
+    h = [l for l in err.splitlines() if l.startswith("bt_model: histograms")][-1]
+    assert int(re.search(r"blocked lane-rounds (\d+)", h).group(1)) > 10000, h    # pipelined same-hash chains: lanes held back by an open slot
