@@ -663,8 +663,22 @@ def run_tree(args, R, spec):
     from csc_amd import sharded, treegen, csa
     root = os.environ.get("CSC_TREE_DIR") or os.path.join(tempfile.gettempdir(), f"csc_tree_{spec}_{os.getuid()}")
     if R.rank == 0:
-        os.makedirs(root, exist_ok=True)
+        # the tree is benchmark INPUT: a private directory of this user, not a link somebody else could have planted, and stamped with
+        # what generated it (a tree of an older generator is rebuilt instead of silently becoming the input)
+        os.makedirs(root, mode=0o700, exist_ok=True)
+        st = os.lstat(root)
+        import stat as _stat
+        if _stat.S_ISLNK(st.st_mode) or not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid():
+            raise SystemExit(f"bench.py: {root} is not a directory owned by this user; set CSC_TREE_DIR")
+        stamp = hashlib.sha256(repr((spec, treegen.SPECS[spec], treegen.files(spec)[:8], treegen.total_bytes(spec),
+                                     open(os.path.join(ROOT, "csc_amd", "csrc", "corpus.c"), "rb").read())).encode()).hexdigest()
+        marker = os.path.join(root, ".csc_tree_stamp")
+        if not (os.path.isfile(marker) and open(marker).read().strip() == stamp):
+            import shutil
+            shutil.rmtree(os.path.join(root, "t"), ignore_errors=True)
         total = treegen.materialize(root, spec)
+        with open(marker, "w") as f:
+            f.write(stamp + "\n")
     R.barrier()
     total = treegen.total_bytes(spec)
     level, dict_size = 3, 64 << 20
