@@ -41,8 +41,10 @@ with open(os.path.join(dst, f"{tag}_pmc.md"), "w") as f:
             f"SALU {tot.get('SQ_INSTS_SALU', 0) / max(1, inp.get('SQ_INSTS_SALU', 1)):.0f}, VALU {tot.get('SQ_INSTS_VALU', 0) / max(1, inp.get('SQ_INSTS_VALU', 1)):.0f}, "
             f"LDS {tot.get('SQ_INSTS_LDS', 0) / max(1, inp.get('SQ_INSTS_LDS', 1)):.0f}, branches {tot.get('SQ_INSTS_BRANCH', 0) / max(1, inp.get('SQ_INSTS_BRANCH', 1)):.0f}.\n"
             f"library sha256[:16] = {so}\n")
-json.dump({"m3_d64m_single_stream": {"fetch_bytes_per_input_byte": round(fetch, 2), "write_bytes_per_input_byte": round(write, 2), "library_sha256_16": so,
-                                     "source": f"profiles/{tag}_pmc.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over `python3 bench.py --steps 2 --warmup 0 "
-                                               "--no-cpu-baseline --multi-streams '' --p8-steps 0 --steady-steps 0`; KiB units; narrow 4-16 byte gathers, so no gfx950 wide-read doubling applied"}},
-          open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=2)
+path = os.path.join(dst, "pmc_traffic.json")
+allk = json.load(open(path)) if os.path.exists(path) else {}
+allk["m3_d64m_single_stream"] = {"fetch_bytes_per_input_byte": round(fetch, 2), "write_bytes_per_input_byte": round(write, 2), "library_sha256_16": so,
+                                 "source": f"profiles/{tag}_pmc.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over `python3 bench.py --steps 2 --warmup 0 "
+                                           "--no-cpu-baseline --multi-streams '' --p8-steps 0 --steady-steps 0`; KiB units; narrow 4-16 byte gathers, so no gfx950 wide-read doubling applied"}
+json.dump(allk, open(path, "w"), indent=2)
 print(open(os.path.join(dst, f"{tag}_pmc.md")).read())
