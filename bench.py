@@ -446,7 +446,7 @@ def run_single(args, R, lib, src, level, dict_size):
     for f, _ in CSCMIStats._fields_:
         setattr(ds, f, getattr(s1, f) - getattr(s0, f))
     bpl = in_b / max(1, launches)
-    line["roofline"] = roofline(level, ratio, launches, kern_ms, in_b, "k_encode_runs_dp4" if level == 3 else "k_encode_runs",
+    line["roofline"] = roofline(level, ratio, launches, kern_ms, in_b, {3: "k_encode_runs_dp4", 5: "k_encode_runs_bt", 1: "k_encode_runs_hp", 2: "k_encode_runs_hp"}.get(level, "k_encode_runs"),
                                 "one stream = one workgroup: the libcsc chain is latency/issue-bound, not bandwidth-bound",
                                 traffic_from_profile(f"m{level}_d{args.dict}_single_stream", bpl), ds)
     line["counters"] = {"find_match_calls": int(ds.find_match_calls), "slide_positions": int(ds.slide_positions),

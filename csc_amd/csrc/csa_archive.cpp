@@ -431,7 +431,9 @@ struct AddJob {
     AdlerSumsH *h_sums = nullptr;
     size_t piece_cap = 0;
     uint64_t raw_bytes = 0;
+    std::vector<uint8_t *> chunk_groups;          // the slots' device chunks, kChunkGroup slots per allocation
 };
+constexpr size_t kChunkGroup = 64;
 
 #define HIP_OK(x) ((x) == hipSuccess)
 
@@ -521,7 +523,6 @@ void free_job(AddJob &J, std::vector<Slot> &slots)
     for (Slot &s : slots) {
         if (s.h) CSCEnc_Destroy(s.h);
         if (s.fd >= 0) close(s.fd);
-        if (s.d_chunk) (void)hipFree(s.d_chunk);
         delete s.sink;
         s = Slot();
     }
@@ -530,6 +531,7 @@ void free_job(AddJob &J, std::vector<Slot> &slots)
         if (J.stage_ev[i]) (void)hipEventDestroy(J.stage_ev[i]);
         J.stage[i] = nullptr; J.stage_ev[i] = nullptr;
     }
+    for (uint8_t *g : J.chunk_groups) (void)hipFree(g);
     if (J.d_pieces) (void)hipFree(J.d_pieces);
     if (J.d_sums) (void)hipFree(J.d_sums);
     if (J.h_sums) (void)hipHostFree(J.h_sums);
@@ -606,7 +608,15 @@ int encode_tasks(std::vector<Task> &tasks, const EmitFn &emit, const CSAOptions 
             if (active && mem_used + mem > budget) break;
             if (free_slot == slots.size()) slots.push_back(Slot());
             Slot &s = slots[free_slot];
-            if (!s.d_chunk && !HIP_OK(hipMalloc((void **)&s.d_chunk, J.raw_blocksize + 64))) { rc = CSCMI_DEVICE_ERROR; break; }
+            if (!s.d_chunk) {
+                const size_t stride = ((size_t)J.raw_blocksize + 64 + 255) & ~(size_t)255;
+                if (free_slot / kChunkGroup >= J.chunk_groups.size()) {
+                    uint8_t *g = nullptr;
+                    if (!HIP_OK(hipMalloc((void **)&g, stride * kChunkGroup))) { rc = CSCMI_DEVICE_ERROR; break; }
+                    J.chunk_groups.push_back(g);
+                }
+                s.d_chunk = J.chunk_groups[free_slot / kChunkGroup] + (free_slot % kChunkGroup) * stride;
+            }
             s.sink = new BlockSink();
             s.h = CSCEnc_Create(&p, &s.sink->os, NULL);
             if (!s.h) { delete s.sink; s.sink = nullptr; rc = CSCMI_DEVICE_ERROR; break; }
@@ -648,14 +658,16 @@ int encode_tasks(std::vector<Task> &tasks, const EmitFn &emit, const CSAOptions 
 
         // ---- streams whose task has no bytes left: EOF, flush, hand the blocks to the writer
         ts = now_s();
+        hs.clear();
+        for (uint32_t i : live) if (slots[i].fi >= tasks[slots[i].task].files.size()) hs.push_back(slots[i].h);
+        rc = CSCMI_FlushBatch((int)hs.size(), hs.data());                   // csa_worker.cpp:49, every finished stream in one round trip
+        if (rc) break;
         for (uint32_t i : live) {
             Slot &s = slots[i];
             Task &t = tasks[s.task];
             if (s.fi < t.files.size()) continue;
-            int r = CSCEnc_Encode_Flush(s.h);                               // csa_worker.cpp:49
             CSCEnc_Destroy(s.h);
             s.h = nullptr;
-            if (r) { rc = r; break; }
             s.sink->finish();                                               // csa_io.h:596-603
             done[s.task] = s.sink;
             s.sink = nullptr;

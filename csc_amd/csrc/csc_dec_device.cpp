@@ -27,6 +27,8 @@ namespace cscmi {
 void launch_decode_init(DecState *D, hipStream_t st);
 void launch_decode_run(DecState *D, hipStream_t st);
 void launch_decode_run_multi(DecState *const *states, uint32_t n, hipStream_t st);
+hipStream_t pooled_stream(int device);                     // csc_host.cpp
+void pooled_stream_release(int device, hipStream_t s);
 }
 using namespace cscmi;
 
@@ -68,7 +70,7 @@ void dec_res_destroy(DecRes *r)
     if (!r) return;
     if (r->dslab) (void)hipFree(r->dslab);
     if (r->hslab) (void)hipHostFree(r->hslab);
-    if (r->stream) (void)hipStreamDestroy(r->stream);
+    if (r->stream) cscmi::pooled_stream_release(r->device, r->stream);
     delete r;
 }
 void dec_cache_trim()
@@ -90,6 +92,8 @@ DecRes *dec_res_get(int device, size_t dsize, size_t hsize)
             if (r->device == device && r->dsize == dsize && r->hsize == hsize) {
                 g_dec_cache.erase(g_dec_cache.begin() + i);
                 g_dec_cache_bytes -= dsize;
+                r->stream = cscmi::pooled_stream(device);      // (a recycled entry holds none while it sits in the cache)
+                if (!r->stream) { dec_res_destroy(r); return nullptr; }
                 return r;
             }
         }
@@ -97,7 +101,7 @@ DecRes *dec_res_get(int device, size_t dsize, size_t hsize)
     DecRes *r = new DecRes();
     memset(r, 0, sizeof(*r));
     r->device = device; r->dsize = dsize; r->hsize = hsize;
-    bool ok = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = (r->stream = cscmi::pooled_stream(device)) != nullptr;     // shared, csc_host.cpp: creating a stream costs ~4 ms here
     if (ok && hipMalloc((void **)&r->dslab, dsize) != hipSuccess) {
         (void)hipGetLastError();
         dec_cache_trim();                                  // give cached slabs back and try once more
@@ -110,6 +114,8 @@ DecRes *dec_res_get(int device, size_t dsize, size_t hsize)
 void dec_res_put(DecRes *r)
 {
     if (!r) return;
+    cscmi::pooled_stream_release(r->device, r->stream);
+    r->stream = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_dec_mu);
         if (g_dec_cache_bytes + r->dsize <= kDecCacheMaxBytes && g_dec_cache.size() < 1024) {

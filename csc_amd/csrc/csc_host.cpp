@@ -35,6 +35,8 @@ void launch_encode_runs_multi(int parser, uint32_t nstreams, EncState *const *st
 #ifdef CSCMI_STAGE_TEST
 void launch_stage_filter(EncState *S, uint32_t kind, uint32_t size, uint32_t chn, uint32_t *result, hipStream_t st);
 #endif
+hipStream_t pooled_stream(int device);
+void pooled_stream_release(int device, hipStream_t s);
 }  // namespace cscmi
 
 using namespace cscmi;
@@ -88,8 +90,6 @@ void build_trie(uint16_t *next, uint8_t *sym)
     }
 }
 
-std::once_flag g_tables_once;
-hipError_t g_tables_err = hipSuccess;
 
 // Per-handle resources that do not depend on the stream's content are recycled: creating a handle
 // costs a pinned allocation, a stream and ~70 events otherwise, and an archive job creates one handle
@@ -101,9 +101,12 @@ struct HostRes {
     size_t hsize;
     uint8_t *hslab;
     uint8_t *h_in;              // lazily allocated: only CSCEnc_Encode / CSCMI_EncodeHostChunk stage input on the host
+    uint8_t *h_arena;           // lazily allocated (drain_arena): where ONE handle's coder blocks are read back to; a batch of handles reads
+    size_t h_arena_cap;         // its blocks back through the calling thread's pool instead (t_batch.pool), so a task stream of the archiver pins no 7 MiB
     hipStream_t stream;
-    hipEvent_t ev[32][2];
+    hipEvent_t ev[32][2];       // created on first use (host_events): a handle that is only ever driven through a batch launch records none
     hipEvent_t ev_an[2];
+    bool have_events;
 };
 struct DevSlab { int device; size_t size; void *p; };
 
@@ -111,45 +114,100 @@ std::mutex g_cache_mu;
 std::vector<HostRes *> g_host_cache;
 std::vector<DevSlab> g_dev_cache;
 size_t g_dev_cache_bytes = 0;
-constexpr size_t kHostCacheMax = 1280;            // entries (~7 MiB pinned each)
+constexpr size_t kHostCacheMax = 4096;            // entries (a stream + ~90 KiB pinned each; + 7 MiB for those that have read blocks back alone)
 constexpr size_t kDevCacheMaxBytes = 48ull << 30;
+
+}  // namespace
+
+// Streams are shared: creating one costs ~4 ms on this runtime (tools/gpu_setup_probe.py), an archive job has thousands of handles
+// alive at once, and a handle's own stream only carries its set-up, its single-handle calls and its EOF -- batch calls run on the
+// lead handle's stream.  Up to kStreamPool non-blocking streams per device, handed out least-used first, created when every
+// existing one has a user, never destroyed.  Handles that share a stream stay correct (every call waits for its own work; it may
+// wait for a neighbour's too): a host that drives more than kStreamPool handles from threads of its own loses overlap, not bytes.
+namespace cscmi {
+namespace {
+constexpr int kStreamPool = 16;
+struct StreamPool { hipStream_t s[kStreamPool]; uint32_t users[kStreamPool]; int n; };
+StreamPool g_streams[64];
+std::mutex g_streams_mu;
+}
+hipStream_t pooled_stream(int device)
+{
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    StreamPool &p = g_streams[device];
+    int best = -1;
+    for (int i = 0; i < p.n; i++) if (best < 0 || p.users[i] < p.users[best]) best = i;
+    if ((best < 0 || p.users[best] > 0) && p.n < kStreamPool) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) { best = p.n++; p.s[best] = st; p.users[best] = 0; }
+        else (void)hipGetLastError();
+    }
+    if (best < 0) return nullptr;
+    p.users[best]++;
+    return p.s[best];
+}
+void pooled_stream_release(int device, hipStream_t s)
+{
+    if (device < 0 || device >= 64 || !s) return;
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    StreamPool &p = g_streams[device];
+    for (int i = 0; i < p.n; i++) if (p.s[i] == s) { if (p.users[i]) p.users[i]--; return; }
+}
+}  // namespace cscmi
+
+namespace {
 
 void host_res_destroy(HostRes *r)
 {
     if (!r) return;
     if (r->hslab) (void)hipHostFree(r->hslab);
     if (r->h_in) (void)hipHostFree(r->h_in);
+    if (r->h_arena) (void)hipHostFree(r->h_arena);
     for (auto &pr : r->ev) for (auto &e : pr) if (e) (void)hipEventDestroy(e);
     for (auto &e : r->ev_an) if (e) (void)hipEventDestroy(e);
-    if (r->stream) (void)hipStreamDestroy(r->stream);
+    if (r->stream) pooled_stream_release(r->device, r->stream);
     delete r;
 }
 
 HostRes *host_res_get(int device, size_t hsize)
 {
+    HostRes *r = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         for (size_t i = 0; i < g_host_cache.size(); i++)
             if (g_host_cache[i]->device == device && g_host_cache[i]->hsize == hsize) {
-                HostRes *r = g_host_cache[i];
+                r = g_host_cache[i];
                 g_host_cache.erase(g_host_cache.begin() + i);
-                return r;
+                break;
             }
     }
-    HostRes *r = new HostRes();
-    memset(r, 0, sizeof(*r));
-    r->device = device; r->hsize = hsize;
-    bool ok = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&r->hslab, hsize, hipHostMallocDefault) == hipSuccess;
-    for (auto &pr : r->ev) for (auto &e : pr) ok = ok && hipEventCreate(&e) == hipSuccess;
-    for (auto &e : r->ev_an) ok = ok && hipEventCreate(&e) == hipSuccess;
-    if (!ok) { host_res_destroy(r); return nullptr; }
+    bool ok = true;
+    if (!r) {
+        r = new HostRes();
+        memset(r, 0, sizeof(*r));
+        r->device = device; r->hsize = hsize;
+        ok = hipHostMalloc((void **)&r->hslab, hsize, hipHostMallocDefault) == hipSuccess;
+    }
+    r->stream = ok ? pooled_stream(device) : nullptr;      // (a recycled entry holds none while it sits in the cache)
+    if (!ok || !r->stream) { host_res_destroy(r); return nullptr; }
     return r;
+}
+
+hipError_t host_events(HostRes *r)
+{
+    if (r->have_events) return hipSuccess;
+    for (auto &pr : r->ev) for (auto &e : pr) if (!e) { hipError_t err = hipEventCreate(&e); if (err != hipSuccess) return err; }
+    for (auto &e : r->ev_an) if (!e) { hipError_t err = hipEventCreate(&e); if (err != hipSuccess) return err; }
+    r->have_events = true;
+    return hipSuccess;
 }
 
 void host_res_put(HostRes *r)
 {
     if (!r) return;
+    pooled_stream_release(r->device, r->stream);
+    r->stream = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         if (g_host_cache.size() < kHostCacheMax) { g_host_cache.push_back(r); return; }
@@ -202,6 +260,34 @@ void dev_slab_put(int device, size_t size, void *p)
     (void)hipFree(p);
 }
 
+// per device, once: the constant tables of the kernels + the two tables built on the host -- the word trie of the dictionary filter
+// (next: u16[7800], sym: u8[300]) and log2(diffNum-2)-0.6 for diffNum 6..15 (csc_analyzer.cpp:223).  Never freed.
+struct DevTables { uint8_t *trie; double *coef; bool ready; };
+DevTables g_dev_tables[64];
+std::mutex g_dev_tables_mu;
+hipError_t device_tables(int device, DevTables &out)
+{
+    if (device < 0 || device >= 64) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(g_dev_tables_mu);
+    DevTables &t = g_dev_tables[device];
+    if (!t.ready) {
+        hipError_t err = upload_tables();
+        if (err != hipSuccess) return err;
+        std::vector<uint8_t> trie(300 * 26 * 2 + 320, 0);
+        build_trie((uint16_t *)trie.data(), trie.data() + 300 * 26 * 2);
+        double coef[16] = {0};
+        for (int d = 6; d < 16; d++) coef[d - 6] = log((double)d - 2) / log((double)2) - 0.6;
+        uint8_t *p = nullptr;
+        const size_t trie_bytes = (trie.size() + 255) & ~(size_t)255;
+        if ((err = hipMalloc((void **)&p, trie_bytes + sizeof(coef))) != hipSuccess) return err;
+        if ((err = hipMemcpy(p, trie.data(), trie.size(), hipMemcpyHostToDevice)) != hipSuccess
+            || (err = hipMemcpy(p + trie_bytes, coef, sizeof(coef), hipMemcpyHostToDevice)) != hipSuccess) { (void)hipFree(p); return err; }
+        t.trie = p; t.coef = (double *)(p + trie_bytes); t.ready = true;
+    }
+    out = t;
+    return hipSuccess;
+}
+
 struct EncInstance {
     uint32_t magic;
     ISzAlloc *alloc;
@@ -219,7 +305,6 @@ struct EncInstance {
     HostRes *res;               // stream, events and the pinned slab the pointers below point into
     // pinned staging
     uint8_t *h_in;
-    uint8_t *h_arena;
     BlockInfo *h_binfo;
     RunDesc *h_runs;
     uint32_t *h_dup;
@@ -244,9 +329,14 @@ struct EncInstance {
 };
 // argument arrays of the multi-stream launch ([4 * kMaxBatch] pointer-sized words: states, run lists, run
 // counts, reset flags), one set per calling thread and device, kept for the life of the thread
-struct BatchArgs { int device = -1; void **d = nullptr; void **h = nullptr; void **d2 = nullptr; void **h2 = nullptr; hipStream_t side = nullptr; };
+// + the pinned pool a batch reads its streams' coder blocks back through (drain_batch), and the {bytes, error} pair of every stream
+struct BatchArgs {
+    int device = -1; void **d = nullptr; void **h = nullptr; void **d2 = nullptr; void **h2 = nullptr; hipStream_t side = nullptr;
+    uint8_t *pool = nullptr; uint32_t *small = nullptr;
+};
 thread_local BatchArgs t_batch;
 constexpr int kMaxBatch = 2048;
+constexpr size_t kBatchPool = 64ull << 20;       // >= the arena of the largest raw_blocksize (3 x 16 MiB + 1 MiB)
 
 void free_device(EncInstance *e)
 {
@@ -286,6 +376,27 @@ int launch_runs(EncInstance *e, uint32_t a, uint32_t b, bool &first_launch, int 
     return 0;
 }
 
+// hand the coder blocks of one chunk (a host copy of the stream's arena) to the user's stream, in the order they were finished
+int write_arena(EncInstance *e, const uint8_t *h_arena, uint32_t used)
+{
+    for (uint32_t off = 0; off < used;) {
+        const ArenaRec *rec = (const ArenaRec *)(h_arena + off);
+        e->outsize += rec->size;
+        e->stats.output_bytes += rec->size;
+        if (write_block(e, h_arena + off + 16, rec->size, rec->kind) < 0) return WRITE_ERROR;
+        off += 16 + ((rec->size + 15) & ~15u);
+    }
+    return 0;
+}
+
+int report_device_error(uint32_t err)
+{
+    // anything else is the watchdog of the multi-wavefront parser (csc_kernels_dp2.inc): the value says which wait gave up
+    fprintf(stderr, "csc-mi355x: device encoder error 0x%x (%s)\n", err,
+            err == ERR_ARENA_FULL ? "output arena exhausted" : err == ERR_BAD_TYPE ? "bad block type" : "parse wavefronts lost step");
+    return CSCMI_DEVICE_ERROR;
+}
+
 // read the finished coder blocks of this chunk back and hand them to the user's stream
 int drain_arena(EncInstance *e, int ev_used)
 {
@@ -296,24 +407,19 @@ int drain_arena(EncInstance *e, int ev_used)
         if (hipEventElapsedTime(&ms, e->ev[i][0], e->ev[i][1]) == hipSuccess) e->stats.encode_kernel_ms += ms;
     }
     uint32_t used = e->h_small[0], err = e->h_small[1];
-    if (err != ERR_NONE) {
-        // anything else is the watchdog of the multi-wavefront parser (csc_kernels_dp2.inc): the value says which wait gave up
-        fprintf(stderr, "csc-mi355x: device encoder error 0x%x (%s)\n", err,
-                err == ERR_ARENA_FULL ? "output arena exhausted" : err == ERR_BAD_TYPE ? "bad block type" : "parse wavefronts lost step");
-        return CSCMI_DEVICE_ERROR;
-    }
+    if (err != ERR_NONE) return report_device_error(err);
     if (used) {
-        HIPCHK(hipMemcpyAsync(e->h_arena, e->h.arena, used, hipMemcpyDeviceToHost, e->stream));
+        HostRes *r = e->res;
+        if (r->h_arena_cap < used) {    // pinned, kept with the recycled host resources; sized for the worst chunk once
+            if (r->h_arena) { (void)hipHostFree(r->h_arena); r->h_arena = nullptr; r->h_arena_cap = 0; }
+            const size_t cap = (size_t)e->h.arena_cap + 64;
+            HIPCHK(hipHostMalloc((void **)&r->h_arena, cap, hipHostMallocDefault));
+            r->h_arena_cap = cap;
+        }
+        HIPCHK(hipMemcpyAsync(r->h_arena, e->h.arena, used, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
     }
-    for (uint32_t off = 0; off < used;) {
-        const ArenaRec *rec = (const ArenaRec *)(e->h_arena + off);
-        e->outsize += rec->size;
-        e->stats.output_bytes += rec->size;
-        if (write_block(e, e->h_arena + off + 16, rec->size, rec->kind) < 0) return WRITE_ERROR;
-        off += 16 + ((rec->size + 15) & ~15u);
-    }
-    return 0;
+    return write_arena(e, e->res->h_arena, used);
 }
 
 // CSCEncoder::Compress, csc_encoder_main.cpp:85-147, with the data work on the device.
@@ -335,11 +441,11 @@ int chunk_begin(EncInstance *e, const void *src, size_t size, bool on_device, hi
 {
     if (size == 0 || size > e->props.raw_blocksize) return -1;
     HIPCHK(hipSetDevice(e->device));
+    const bool timed = st == nullptr;                // (a batch queues every stream's analyzer on the lead's stream: not timed one by one)
     if (!st) st = e->stream;
     if (!host_segment()) {
         HIPCHK(hipMemcpyAsync(e->h.inbuf, src, size, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         if ((e->props.DLTFilter + e->props.EXEFilter + e->props.TXTFilter) != 0) {
-            const bool timed = st == e->stream;          // (a batch queues every stream's analyzer on the lead's stream: not timed one by one)
             if (timed) HIPCHK(hipEventRecord(e->ev_an[0], st));
             launch_analyze(e->d_state, (uint32_t)size, e->d_entcoef, st);
             HIPCHK(hipGetLastError());
@@ -464,6 +570,8 @@ int chunk_segment(EncInstance *e, size_t size, bool defer_final)
 int encode_chunk(EncInstance *e, const void *src, size_t size, bool on_device)
 {
     if (size == 0) return 0;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(host_events(e->res));
     int rc = chunk_begin(e, src, size, on_device);
     if (rc) return rc;
     if (!host_segment()) {
@@ -483,6 +591,71 @@ int encode_chunk(EncInstance *e, const void *src, size_t size, bool on_device)
     rc = chunk_segment(e, size, false);
     if (rc) return rc;
     return drain_arena(e, e->pend_ev);
+}
+
+// the calling thread's launch tables + read-back pool, on `device`
+int batch_args_ready(int device)
+{
+    if (t_batch.device == device) return 0;
+    if (t_batch.d) (void)hipFree(t_batch.d);
+    if (t_batch.h) (void)hipHostFree(t_batch.h);
+    if (t_batch.d2) (void)hipFree(t_batch.d2);
+    if (t_batch.h2) (void)hipHostFree(t_batch.h2);
+    if (t_batch.side) (void)hipStreamDestroy(t_batch.side);
+    if (t_batch.pool) (void)hipHostFree(t_batch.pool);
+    if (t_batch.small) (void)hipHostFree(t_batch.small);
+    t_batch = BatchArgs();
+    HIPCHK(hipMalloc((void **)&t_batch.d, sizeof(void *) * 4 * kMaxBatch));
+    HIPCHK(hipHostMalloc((void **)&t_batch.h, sizeof(void *) * 4 * kMaxBatch, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void **)&t_batch.d2, sizeof(void *) * 4 * kMaxBatch));
+    HIPCHK(hipHostMalloc((void **)&t_batch.h2, sizeof(void *) * 4 * kMaxBatch, hipHostMallocDefault));
+    HIPCHK(hipStreamCreateWithFlags(&t_batch.side, hipStreamNonBlocking));
+    HIPCHK(hipHostMalloc((void **)&t_batch.pool, kBatchPool, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&t_batch.small, sizeof(uint32_t) * 2 * kMaxBatch, hipHostMallocDefault));
+    t_batch.device = device;
+    return 0;
+}
+
+// Read the coder blocks of hs[i] (every i with skip == nullptr || skip[i] != 0) back and hand them to the users' streams, in handle
+// order: the {bytes, error} pairs of all streams with one wait, then the arenas packed into the thread's pinned pool, one wait per
+// pool-full.  All copies on `st`, the stream the kernels that filled the arenas were launched on.
+int drain_batch(int n, CSCEncHandle *hs, const size_t *skip, hipStream_t st)
+{
+    uint32_t *sm = t_batch.small;
+    for (int i = 0; i < n; i++) {
+        if (skip && !skip[i]) continue;
+        EncInstance *e = (EncInstance *)hs[i];
+        HIPCHK(hipMemcpyAsync(sm + 2 * i, &e->d_state->arena_used, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    int rc = 0;
+    for (int i = 0; i < n; i++) {
+        if (skip && !skip[i]) continue;
+        if (sm[2 * i + 1] != ERR_NONE) rc = report_device_error(sm[2 * i + 1]);
+        else if ((size_t)sm[2 * i] > kBatchPool) { fprintf(stderr, "csc-mi355x: a stream's coder blocks exceed the read-back pool\n"); rc = CSCMI_DEVICE_ERROR; }
+    }
+    if (rc) return rc;
+    std::vector<size_t> at((size_t)n, 0);
+    for (int i = 0; i < n;) {
+        size_t off = 0;
+        int j = i;
+        for (; j < n; j++) {
+            if (skip && !skip[j]) continue;
+            const size_t used = sm[2 * j];
+            if (off + used > kBatchPool) break;
+            at[j] = off;
+            if (used) HIPCHK(hipMemcpyAsync(t_batch.pool + off, ((EncInstance *)hs[j])->h.arena, used, hipMemcpyDeviceToHost, st));
+            off += (used + 255) & ~(size_t)255;
+        }
+        HIPCHK(hipStreamSynchronize(st));
+        for (int k = i; k < j; k++) {
+            if (skip && !skip[k]) continue;
+            int r = write_arena((EncInstance *)hs[k], t_batch.pool + at[k], sm[2 * k]);
+            if (r && !rc) rc = r;
+        }
+        i = j;
+    }
+    return rc;
 }
 
 }  // namespace
@@ -567,7 +740,6 @@ CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *outstream, ISzA
         fprintf(stderr, "csc-mi355x: unsupported CSCProps\n");
         return NULL;
     }
-    std::call_once(g_tables_once, [] { g_tables_err = upload_tables(); });
 
     EncInstance *e = (EncInstance *)alloc->Alloc(alloc, sizeof(EncInstance));
     if (!e) return NULL;
@@ -587,7 +759,8 @@ CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *outstream, ISzA
     }
     bool ok = hipGetDevice(&e->device) == hipSuccess;
     // each process/thread may sit on another device: the constant tables are per device
-    if (ok) ok = upload_tables() == hipSuccess;
+    DevTables dt = {nullptr, nullptr, false};
+    if (ok) ok = device_tables(e->device, dt) == hipSuccess;
 
     EncState &h = e->h;
     // LZ::Init / MatchFinder::Init geometry, csc_lz.cpp:15-33, csc_mf.cpp:45-106
@@ -617,14 +790,14 @@ CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *outstream, ISzA
     const size_t o_rc = dtake((size_t)h.bsize + 64), o_bc = dtake((size_t)h.bsize + 64);
     const size_t o_in = dtake((size_t)h.raw_blocksize + 256), o_swap = dtake(4 * (size_t)h.raw_blocksize + 512);
     const size_t o_arena = dtake((size_t)h.arena_cap + 64), o_binfo = dtake(sizeof(BlockInfo) * kMaxBlocksPerChunk);
-    const size_t o_dup = dtake(sizeof(uint32_t) * kMaxBlocksPerChunk), o_trie = dtake(300 * 26 * 2 + 320);
-    const size_t o_runs = dtake(sizeof(RunDesc) * (kMaxBlocksPerChunk + 2)), o_coef = dtake(sizeof(double) * 16);
+    const size_t o_dup = dtake(sizeof(uint32_t) * kMaxBlocksPerChunk);
+    const size_t o_runs = dtake(sizeof(RunDesc) * (kMaxBlocksPerChunk + 2));
     const size_t o_state = dtake(sizeof(EncState));
     e->dsize = doff;
     // ---- one pinned slab
     size_t hoff = 0;
     auto htake = [&](size_t bytes) { size_t o = hoff; hoff += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t p_arena = htake((size_t)h.arena_cap + 64), p_binfo = htake(sizeof(BlockInfo) * kMaxBlocksPerChunk);
+    const size_t p_binfo = htake(sizeof(BlockInfo) * kMaxBlocksPerChunk);
     const size_t p_runs = htake(sizeof(RunDesc) * (kMaxBlocksPerChunk + 2)), p_dup = htake(sizeof(uint32_t) * kMaxBlocksPerChunk);
     const size_t p_small = htake(64);
 
@@ -635,10 +808,10 @@ CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *outstream, ISzA
         uint8_t *D = (uint8_t *)e->dslab, *H = e->res->hslab;
         h.wnd = D + o_wnd; h.mfbuf = (uint32_t *)(D + o_mf); h.p_lit = (uint32_t *)(D + o_plit); h.p_delta = (uint32_t *)(D + o_pdelta);
         h.rc_buf = D + o_rc; h.bc_buf = D + o_bc; h.inbuf = D + o_in; h.swapbuf = D + o_swap; h.arena = D + o_arena;
-        h.binfo = (BlockInfo *)(D + o_binfo); h.dup_flags = (uint32_t *)(D + o_dup); e->d_trie = D + o_trie;
-        e->d_runs = (RunDesc *)(D + o_runs); e->d_entcoef = (double *)(D + o_coef); e->d_state = (EncState *)(D + o_state);
+        h.binfo = (BlockInfo *)(D + o_binfo); h.dup_flags = (uint32_t *)(D + o_dup); e->d_trie = dt.trie;
+        e->d_runs = (RunDesc *)(D + o_runs); e->d_entcoef = dt.coef; e->d_state = (EncState *)(D + o_state);
         e->h_in = e->res->h_in;
-        e->h_arena = H + p_arena; e->h_binfo = (BlockInfo *)(H + p_binfo); e->h_runs = (RunDesc *)(H + p_runs);
+        e->h_binfo = (BlockInfo *)(H + p_binfo); e->h_runs = (RunDesc *)(H + p_runs);
         e->h_dup = (uint32_t *)(H + p_dup); e->h_small = (uint32_t *)(H + p_small);
         ok = hipMemsetAsync(e->dslab, 0, e->dsize, e->stream) == hipSuccess;
     }
@@ -658,21 +831,12 @@ CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *outstream, ISzA
     h.trie_next = (const uint16_t *)e->d_trie;
     h.trie_sym = e->d_trie + 300 * 26 * 2;
 
-    // the two host-side tables: word trie, and log2(diffNum-2)-0.6 for diffNum 6..15 (csc_analyzer.cpp:223)
-    {
-        std::vector<uint8_t> trie(300 * 26 * 2 + 320, 0);
-        build_trie((uint16_t *)trie.data(), trie.data() + 300 * 26 * 2);
-        double coef[16] = {0};
-        for (int d = 6; d < 16; d++) coef[d - 6] = log((double)d - 2) / log((double)2) - 0.6;
-        ok = hipMemcpyAsync(e->d_trie, trie.data(), trie.size(), hipMemcpyHostToDevice, st) == hipSuccess
-          && hipMemcpyAsync(e->d_entcoef, coef, sizeof(coef), hipMemcpyHostToDevice, st) == hipSuccess
-          && hipMemcpyAsync(e->d_state, &h, sizeof(EncState), hipMemcpyHostToDevice, st) == hipSuccess;
-        if (ok) {
-            launch_init_state(e->d_state, st);
-            ok = hipGetLastError() == hipSuccess;
-        }
-        ok = ok && hipStreamSynchronize(st) == hipSuccess && g_tables_err == hipSuccess;   // the sources above are locals
+    ok = hipMemcpyAsync(e->d_state, &h, sizeof(EncState), hipMemcpyHostToDevice, st) == hipSuccess;
+    if (ok) {
+        launch_init_state(e->d_state, st);
+        ok = hipGetLastError() == hipSuccess;
     }
+    ok = ok && hipStreamSynchronize(st) == hipSuccess;   // (`h` may change once this returns)
     if (!ok) {
         fprintf(stderr, "csc-mi355x: device initialisation failed (%s)\n", hipGetErrorString(hipGetLastError()));
         free_device(e);
@@ -710,20 +874,8 @@ int CSCMI_EncodeDeviceChunkBatch(int n, CSCEncHandle *hs, const void *const *dev
     if (n > kMaxBatch) return -1;
     EncInstance *lead = (EncInstance *)hs[0];
     HIPCHK(hipSetDevice(lead->device));
-    if (t_batch.device != lead->device) {
-        if (t_batch.d) (void)hipFree(t_batch.d);
-        if (t_batch.h) (void)hipHostFree(t_batch.h);
-        if (t_batch.d2) (void)hipFree(t_batch.d2);
-        if (t_batch.h2) (void)hipHostFree(t_batch.h2);
-        if (t_batch.side) (void)hipStreamDestroy(t_batch.side);
-        t_batch = BatchArgs();
-        HIPCHK(hipMalloc((void **)&t_batch.d, sizeof(void *) * 4 * kMaxBatch));
-        HIPCHK(hipHostMalloc((void **)&t_batch.h, sizeof(void *) * 4 * kMaxBatch, hipHostMallocDefault));
-        HIPCHK(hipMalloc((void **)&t_batch.d2, sizeof(void *) * 4 * kMaxBatch));
-        HIPCHK(hipHostMalloc((void **)&t_batch.h2, sizeof(void *) * 4 * kMaxBatch, hipHostMallocDefault));
-        HIPCHK(hipStreamCreateWithFlags(&t_batch.side, hipStreamNonBlocking));
-        t_batch.device = lead->device;
-    }
+    { int r = batch_args_ready(lead->device); if (r) return r; }
+    HIPCHK(host_events(lead->res));
     void **const d_batch = t_batch.d, **const h_batch = t_batch.h;
     int rc = 0;
     static const bool trace = getenv("CSCMI_BATCH_TRACE") != nullptr;      // development: one line per round on stderr
@@ -770,12 +922,12 @@ int CSCMI_EncodeDeviceChunkBatch(int n, CSCEncHandle *hs, const void *const *dev
             EncInstance *e = (EncInstance *)hs[i];
             e->stats.chunks++;
             e->stats.input_bytes += sizes[i];
-            int r = drain_arena(e, 0);
-            if (r && !rc) rc = r;
         }
+        rc = drain_batch(n, hs, sizes, lead->stream);
         if (trace) fprintf(stderr, "batch trace: %d streams, kernels walk their chunks: launches %.1f ms, drain %.1f ms\n", n, tms(t_begin, t_dr), tms(t_dr, tnow()));
         return rc;
     }
+    for (int i = 0; i < n; i++) HIPCHK(host_events(((EncInstance *)hs[i])->res));
     for (int i = 0; i < n && !rc; i++) rc = sizes[i] ? chunk_begin((EncInstance *)hs[i], device_ptrs[i], sizes[i], true) : 0;
     const auto t_cb = tnow();
     for (int i = 0; i < n && !rc; i++) rc = sizes[i] ? seg_begin((EncInstance *)hs[i]) : 0;
@@ -940,6 +1092,28 @@ int CSCEnc_Encode_Flush(CSCEncHandle p)
     HIPCHK(hipGetLastError());
     int ev_used = 0;
     return drain_arena(e, ev_used);
+}
+
+// CSCEnc_Encode_Flush for many handles of one device: every EOF kernel queued on one stream, one wait, the last blocks handed to
+// the users' streams in handle order.  (2048 task streams of the archiver: one round trip instead of 2048.)
+int CSCMI_FlushBatch(int n, CSCEncHandle *hs)
+{
+    if (n <= 0) return 0;
+    EncInstance *lead = (EncInstance *)hs[0];
+    HIPCHK(hipSetDevice(lead->device));
+    for (int i = 0; i < n; i += kMaxBatch) {
+        const int m = n - i < kMaxBatch ? n - i : kMaxBatch;
+        { int r = batch_args_ready(lead->device); if (r) return r; }
+        for (int k = 0; k < m; k++) {
+            EncInstance *e = (EncInstance *)hs[i + k];
+            if (e->device != lead->device) return -1;
+            launch_encode_eof(e->d_state, lead->stream);
+        }
+        HIPCHK(hipGetLastError());
+        int r = drain_batch(m, hs + i, nullptr, lead->stream);
+        if (r) return r;
+    }
+    return 0;
 }
 
 void CSCMI_GetStats(CSCEncHandle p, CSCMIStats *out)

@@ -98,6 +98,10 @@ int CSCMI_EncodeDeviceChunk(CSCEncHandle p, const void *device_ptr, size_t size)
 /* n independent handles (tasks of a -p / per-extension split) advanced by one chunk each with ONE kernel
  * launch, one workgroup per stream; handles must live on the current device.  sizes[i] == 0 skips handle i. */
 int CSCMI_EncodeDeviceChunkBatch(int n, CSCEncHandle *hs, const void *const *device_ptrs, const size_t *sizes);
+/* CSCEnc_Encode_Flush (csc_enc.cpp:193-203) for n handles of the current device with one round trip: the EOF kernels queued on one
+ * stream, one wait, the last coder blocks handed to the handles' output streams on this thread, in handle order.  Returns 0 or
+ * the first error; the streams are byte for byte what n CSCEnc_Encode_Flush calls write. */
+int CSCMI_FlushBatch(int n, CSCEncHandle *hs);
 /* CSCDec_Decode for n independent handles at once: one kernel launch per round advances every stream (one
  * workgroup each); block reads and Write calls happen on the calling thread, per stream in the order CSCDec_Decode
  * would make them.  rcs[i] = what CSCDec_Decode(hs[i], oss[i], NULL) would return.  Returns 0 or CSCMI_DEVICE_ERROR. */
