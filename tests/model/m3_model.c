@@ -298,8 +298,76 @@ static void m3_perm_ids(int *out, const int *in, uint32_t code, int newid)
     } else { out[0] = newid; out[1] = in[0]; out[2] = in[1]; out[3] = in[2]; }
 }
 
+/* ---- the way out's literal trees on a wavefront of their own (csc_kernels_dp4.inc: d6_literal / d6_trees / d6_join) ----
+ * The kernel codes a literal's flag when the packet's turn comes and leaves its eight tree decisions to another wavefront, which
+ * takes whatever records are there, up to eight at a time: one gather of the batch's cells, same-cell literals chained in registers
+ * (the later one starts from the earlier one's updated probability, the last one stores), one scatter.  It waits for the trees only
+ * where p_lit is read (a window's literal prices) and at the sub-block's end.  Shadowed here: the oracle codes the literal at once; a
+ * second copy of p_lit takes the deferred batches (batch sizes 1..8 from a seeded generator: how many records a batch finds is a
+ * matter of timing on the GPU, the result must not depend on it), and at every join every decision's probability and every touched
+ * cell must equal the oracle's.  That is the whole argument: only literals touch p_lit, so their updates commute with every other
+ * packet's. */
+#define M3_LT_MAX 4096
+static struct { uint32_t ctx, sym, pold[8]; } m3_lt[M3_LT_MAX];
+static uint32_t m3_lt_n, m3_lt_seed = 12345u;
+static uint32_t *m3_sh_plit;
+static unsigned long long m3_lt_batches, m3_lt_chained, m3_lt_joins, m3_lt_max_pending;
+
+static uint32_t m3_p_update(uint32_t bit, uint32_t p) { return bit ? p + ((0xFFF - p) >> 5) : p - (p >> 5); }
+
+static void m3_join(OrcEnc *e)
+{
+    if (!m3_lt_n) return;
+    m3_lt_joins++;
+    if (m3_lt_n > m3_lt_max_pending) m3_lt_max_pending = m3_lt_n;
+    for (uint32_t done = 0; done < m3_lt_n;) {
+        m3_lt_seed = m3_lt_seed * 1664525u + 1013904223u;
+        const uint32_t n = UMIN(m3_lt_n - done, 1u + ((m3_lt_seed >> 24) & 7u));
+        uint32_t cell[8][8], bit[8][8], pold[8][8], pnew[8][8];
+        for (uint32_t i = 0; i < n; i++) for (uint32_t k = 0; k < 8; k++) {                 /* the gather: every lane before any update */
+            const uint32_t cc = m3_lt[done + i].sym | 0x100u;
+            cell[i][k] = m3_lt[done + i].ctx * 256u + (cc >> (8u - k)); bit[i][k] = (cc >> (7u - k)) & 1u;
+            pold[i][k] = m3_sh_plit[cell[i][k]];
+        }
+        for (uint32_t i = 0; i < n; i++) for (uint32_t k = 0; k < 8; k++) {                 /* chains in literal order; same cell => same level */
+            int prev = -1;
+            for (int j = (int)i - 1; j >= 0 && prev < 0; j--) if (cell[j][k] == cell[i][k]) prev = j;
+            if (prev >= 0) { pold[i][k] = pnew[prev][k]; m3_lt_chained++; }
+            pnew[i][k] = m3_p_update(bit[i][k], pold[i][k]);
+            if (pold[i][k] != m3_lt[done + i].pold[k]) m3_die("a deferred tree decision saw another probability than the oracle's");
+        }
+        for (uint32_t i = 0; i < n; i++) for (uint32_t k = 0; k < 8; k++) {                 /* the scatter: the last literal on a cell stores */
+            int later = 0;
+            for (uint32_t j = i + 1; j < n; j++) if (cell[j][k] == cell[i][k]) later = 1;
+            if (!later) m3_sh_plit[cell[i][k]] = pnew[i][k];
+        }
+        for (uint32_t i = 0; i < n; i++) for (uint32_t k = 0; k < 8; k++)
+            if (cell[i][k] / 256u != m3_lt[done + i].ctx) m3_die("tree cell outside its context row");
+        done += n;
+        m3_lt_batches++;
+    }
+    for (uint32_t i = 0; i < m3_lt_n; i++) for (uint32_t k = 0; k < 8; k++) {
+        const uint32_t c = m3_lt[i].ctx * 256u + ((m3_lt[i].sym | 0x100u) >> (8u - k));
+        if (m3_sh_plit[c] != e->p_lit[c]) m3_die("p_lit after the deferred batches differs from the oracle's");
+    }
+    m3_lt_n = 0;
+}
+
+static void m3_literal(OrcEnc *e, uint32_t c)
+{
+    if (m3_lt_n == M3_LT_MAX) m3_join(e);
+    const uint32_t cc = c | 0x100u;
+    m3_lt[m3_lt_n].ctx = e->ctx; m3_lt[m3_lt_n].sym = c;
+    for (uint32_t k = 0; k < 8; k++) m3_lt[m3_lt_n].pold[k] = e->p_lit[e->ctx * 256u + (cc >> (8u - k))];
+    m3_lt_n++;
+    encode_literal(e, c);
+}
+
 static void m3_adv(OrcEnc *e, uint32_t size)
 {
+    /* nothing is pending between sub-blocks; other block types may have coded literals meanwhile */
+    if (!m3_sh_plit) m3_sh_plit = (uint32_t *)malloc(256 * 256 * sizeof(uint32_t));
+    memcpy(m3_sh_plit, e->p_lit, 256 * 256 * sizeof(uint32_t));
     const uint32_t W = UMIN(e->ht_width, e->ht_cyc);
     if (e->bt_head || !e->ht_width || W > M3_NS - 2 || e->lz_good_len > M3_RING || e->lz_good_len < 2 || size == 0
         || e->pos >= 0xFFFF0000u) { lz_compress_advanced(e, size); return; }
@@ -451,6 +519,7 @@ static void m3_adv(OrcEnc *e, uint32_t size)
             /* ---- relaxation: lane 1 literal then rep0len1 (:301-313), lanes 2.. the match lengths (:315-326) ---- */
             {
                 const uint32_t lit_ctx = wpos ? e->wnd[wpos - 1] : 0;
+                m3_join(e);                                                     /* (a window's literal prices read p_lit) */
                 const uint32_t tree = literal_price(e, cur.state, lit_ctx, e->wnd[wpos]) - lit_flag[cur.state];
                 uint32_t c1 = tree + lit_flag[cur.state] + cur.price, k1 = 0;
                 if (has1 && p1flag[cur.state] + cur.price < c1) { c1 = p1flag[cur.state] + cur.price; k1 = 1; }
@@ -478,7 +547,7 @@ static void m3_adv(OrcEnc *e, uint32_t size)
         /* ---- way out: back-trace over the log (csc_lz.cpp:335-362), then what the exit itself codes ---- */
         const uint32_t end = k;
         if (exit_kind == 4) {
-            encode_literal(e, e->wnd[M.sb0 + w0]);
+            m3_literal(e, e->wnd[M.sb0 + w0]);
             M.n_direct_lit++;
             i++;
             continue;
@@ -488,7 +557,7 @@ static void m3_adv(OrcEnc *e, uint32_t size)
             for (uint32_t t = end; t;) { nxt[fin_back[t]] = t; t = fin_back[t]; }
             for (uint32_t t = 0; t != end;) {
                 const uint32_t next = nxt[t], nd = fin_dist[next];
-                if (nd == 0) encode_literal(e, e->wnd[M.sb0 + w0 + t]);
+                if (nd == 0) m3_literal(e, e->wnd[M.sb0 + w0 + t]);
                 else if (nd <= 4) {
                     if (next - t == 1 && nd == 1) encode_rep0len1(e);
                     else encode_rep_match(e, nd - 1, next - t - 2);
@@ -505,7 +574,7 @@ static void m3_adv(OrcEnc *e, uint32_t size)
         }
         i += end;
         if (exit_kind == 2) {
-            encode_literal(e, e->wnd[M.sb0 + i]);
+            m3_literal(e, e->wnd[M.sb0 + i]);
             i++;
         } else if (exit_kind == 3) {
             MFUnit u; u.len = a0l; u.dist = a0code;
@@ -518,6 +587,7 @@ static void m3_adv(OrcEnc *e, uint32_t size)
             e->ctx = e->wnd[M.sb0 + i - 1];
         }
     }
+    m3_join(e);
     /* whatever the parser never reached was inserted speculatively beyond the sub-block?  No: the pre-pass stops at `size` */
     if (M.ih < size) m3_ensure(e, size - 1);
     if (M.ih != size) m3_die("inserter did not end at the sub-block end");
@@ -532,6 +602,8 @@ static void m3_stats_atexit(void)
     fprintf(stderr, "m3_model: nodes %llu windows %llu direct-literals %llu | slide events %llu (len>129: %llu, same-hash: %llu) deviations %llu undone positions %llu exact positions %llu | "
             "batches %llu | mask refreshes %llu slow-path rep compares %llu | nodes with a rep length >= 2: %llu, else hash candidates pushed 0/1/2/3+: %llu/%llu/%llu/%llu | spine/edge merges checked %llu\n",
             M.n_nodes, M.n_windows, M.n_direct_lit, M.n_slide, M.n_len_gt129, M.n_hdev_events, M.n_dev, M.n_undo_pos, M.n_exact_pos, M.n_batches, M.n_refresh, M.n_slow, M.n_repnodes, M.n_h0, M.n_h1, M.n_h2, M.n_h3p, M.n_split_checked);
+    fprintf(stderr, "m3_model: literal trees: joins %llu, deferred batches %llu, chained decisions %llu, most records pending at a join %llu\n",
+            m3_lt_joins, m3_lt_batches, m3_lt_chained, m3_lt_max_pending);
 }
 
 __attribute__((constructor)) static void m3_install(void)

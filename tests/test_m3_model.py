@@ -67,11 +67,18 @@ print("MODEL_OK", n)
 ])
 def test_model_equals_oracle(built, knobs):
     err = run_cases(knobs)
-    line = [l for l in err.splitlines() if l.startswith("m3_model:")]
+    line = [l for l in err.splitlines() if l.startswith("m3_model: nodes")]
     assert line, err[-500:]
     # the paths the kernel's exactness rests on must have been walked
     import re
     s = line[-1]
+    # the way out's literal trees, deferred and batched as the tree wavefront does it (d6_literal / d6_trees / d6_join), gave the oracle's
+    # probabilities at every decision and the oracle's p_lit at every join (the model aborts otherwise): batches of 1..8 records, chains inside
+    t = [l for l in err.splitlines() if l.startswith("m3_model: literal trees")][-1]
+    assert int(re.search(r"joins (\d+)", t).group(1)) > 1000, t
+    assert int(re.search(r"deferred batches (\d+)", t).group(1)) > 10000, t
+    assert int(re.search(r"chained decisions (\d+)", t).group(1)) > 1000, t       # same context + common prefix inside a batch
+    assert int(re.search(r"most records pending at a join (\d+)", t).group(1)) > 8, t
     assert int(re.search(r"deviations (\d+)", s).group(1)) > 0, s          # speculative inserts undone + replayed
     assert int(re.search(r"slide events (\d+)", s).group(1)) > 100, s
     assert int(re.search(r"mask refreshes (\d+)", s).group(1)) > 100, s
