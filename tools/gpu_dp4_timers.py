@@ -26,7 +26,7 @@ dt = time.time() - t0
 st = St(); lib.lib.CSCMI_GetStats.argtypes = [C.c_void_p, C.c_void_p]; lib.lib.CSCMI_GetStats(h, C.byref(st))
 lib.lib.CSCMI_DebugTimers.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 tm = (C.c_uint64 * 16)(); lib.lib.CSCMI_DebugTimers(h, tm)
-names = ["wait: slide acknowledged", "window function (DP nodes)", "exit: back-trace", "way out: packets into lanes", "literal flags (incl. the window-less literals)", "literal trees, eight at a time", "exit: length, event, rebase", "way out: match / rep packets, exit packet",
+names = ["wait: slide acknowledged", "window function (DP nodes)", "exit: back-trace", "way out: packets into lanes", "literal flags (incl. the window-less literals)", "waiting for the tree wavefront (d6_join)", "exit: length, event, rebase", "way out: match / rep packets, exit packet",
          "# deviations (undo + replay)", "# rep lengths by compare", "wait record (cyc/16)", "# record waits", "wait literal price (cyc/16)", "# literal waits", "# nodes on the straight-line path", "# waits for a re-based mask (id guard)"]
 tot = sum(tm[:8])
 print(f"{len(data)/1e6/dt:.3f} MB/s, kernel {st.encode_kernel_ms:.0f} ms, nodes {st.find}, slid {st.slide}, lit {st.lit}, match {st.match}")

@@ -37,7 +37,7 @@ with open(os.path.join(dst, f"{tag}_pmc.md"), "w") as f:
         f.write(f"| {k} | {tot[k]:.0f} | {per * (1024 if k in ('FETCH_SIZE', 'WRITE_SIZE') else 1):.3f}{' B' if k in ('FETCH_SIZE', 'WRITE_SIZE') else ''} |\n")
     f.write(f"\nHBM traffic: {fetch:.1f} B read + {write:.1f} B written per input byte (algorithmic: 42.24 B/B).  "
             f"L2: {100 * tot.get('TCC_HIT_sum', 0) / max(1, tot.get('TCC_HIT_sum', 0) + tot.get('TCC_MISS_sum', 0)):.1f} % hits.\n"
-            f"Wave-instructions per input byte (all eight working wavefronts of the stream's workgroup, their polling loops included): "
+            f"Wave-instructions per input byte (all nine working wavefronts of the stream's workgroup, their polling loops included): "
             f"SALU {tot.get('SQ_INSTS_SALU', 0) / max(1, inp.get('SQ_INSTS_SALU', 1)):.0f}, VALU {tot.get('SQ_INSTS_VALU', 0) / max(1, inp.get('SQ_INSTS_VALU', 1)):.0f}, "
             f"LDS {tot.get('SQ_INSTS_LDS', 0) / max(1, inp.get('SQ_INSTS_LDS', 1)):.0f}, branches {tot.get('SQ_INSTS_BRANCH', 0) / max(1, inp.get('SQ_INSTS_BRANCH', 1)):.0f}.\n"
             f"library sha256[:16] = {so}\n")
