@@ -270,6 +270,55 @@ def test_two_handles_interleaved(prod):
     assert outs[0] == prod.encode(a, 3, len(a))[1] and outs[1] == prod.encode(b, 3, len(b))[1]
 
 
+def test_forty_handles_from_eight_threads_share_streams(prod, orc, zalloc):
+    """Handles draw their HIP stream from a pool of at most 16 per device (csc_host.cpp, pooled_stream): 40 handles alive at once, driven
+    chunk by chunk from 8 threads (csarc's worker count, csarc.cpp:348-351) through the single-handle calls, share streams -- every call
+    waits for its own work and may wait for a neighbour's.  Same bytes as the oracle's for every stream; decoders created meanwhile
+    draw from the same pool."""
+    import threading
+    from csc_amd.capi import BytesWriter
+    L = prod.lib
+    L.CSCMI_EncodeHostChunk.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    datas = [cases.build([["exe" if i % 3 == 2 else "text", 700 + i, (i % 5) * 10000, 150000 + 9000 * i]]) for i in range(40)]
+    hs = []
+    for i, d in enumerate(datas):
+        p = prod.props_init(len(d), 1 + i % 5)
+        w = BytesWriter()
+        h = L.CSCEnc_Create(C.byref(p), C.cast(w.ptr(), C.c_void_p), None)
+        assert h
+        w.out += prod.write_properties(p)
+        hs.append((h, w))
+    errs = []
+
+    def work(t):
+        try:
+            for i in range(t, 40, 8):
+                h, w = hs[i]
+                d = datas[i]
+                for off in range(0, len(d), 65536 * 3):
+                    n = min(65536 * 3, len(d) - off)
+                    if L.CSCMI_EncodeHostChunk(h, d[off:off + n], n) != 0:
+                        errs.append(("chunk", i))
+                if t == 0 and i == 0:
+                    rc, raw = prod.decode(orc.encode(datas[1], 3, len(datas[1]), alloc=zalloc)[1])
+                    if rc != 0 or raw != datas[1]:
+                        errs.append(("decode", i))
+        except Exception as ex:       # noqa: BLE001 -- reported below, on the test's thread
+            errs.append(("exception", repr(ex)))
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for th in ths: th.start()
+    for th in ths: th.join()
+    assert not errs, errs
+    for i, (h, w) in enumerate(hs):
+        assert L.CSCEnc_Encode_Flush(h) == 0
+        L.CSCEnc_Destroy(h)
+    for i, d in enumerate(datas):
+        # chunked by 192 KiB: the stream is CSCEncoder::Compress per chunk, which the oracle reproduces with max_read
+        want = orc.encode(d, 1 + i % 5, len(d), alloc=zalloc, max_read=65536 * 3)[1]
+        assert bytes(hs[i][1].out) == want, i
+
+
 def test_batch_of_streams_equals_one_by_one(prod):
     """CSCMI_EncodeDeviceChunkBatch: 12 task streams (a -p12 split incl. a short last slice and an EXE-typed one)
     advanced chunk by chunk with one launch per step == each stream encoded alone."""
