@@ -589,7 +589,8 @@ def run_split(args, R, lib, src, level, dict_size, split, steps, warmup, with_cp
         # launch count and HIP-event kernel time accrue on the batch's lead handle only, so the sums are the lead's
         nl = max(1, s1.encode_launches - s0.encode_launches)
         line["roofline"] = roofline(level, ratio, s1.encode_launches - s0.encode_launches, s1.encode_kernel_ms - s0.encode_kernel_ms,
-                                    (s1.input_bytes - s0.input_bytes), "k_encode_runs_multi_dp4" if level == 3 else "k_encode_runs_multi*",
+                                    (s1.input_bytes - s0.input_bytes), # (which form a launch takes: csc_kernels_blocks.inc, launch_encode_runs_multi -- the pipeline form holds one stream a CU)
+                                    ("k_encode_runs_multi_dp4" if S <= 256 else "k_encode_runs_multi<3,true> (one parse wavefront a stream, four streams a CU)") if level == 3 else "k_encode_runs_multi*",
                                     f"rank 0's GPU: {S} streams per launch, one workgroup each; per-launch time from HIP events on the launch stream",
                                     traffic_from_profile(f"m{level}_d{args.dict}_p{split}", (s1.input_bytes - s0.input_bytes) / nl) if R.world == 1 else (None, "PMC passes are recorded for N = 1"))
         line["tasks_per_rank"] = [len(a) for a in tasks.assign(slices, R.world)]
