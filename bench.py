@@ -258,8 +258,11 @@ def multi_stream_job(lib, src, stream_counts, level, dict_size):
                 return {"multi_stream": f"batch encode failed rc={rc}"}
             total += sum(Z)
             k += 1
-        for h in hs:
-            L.CSCEnc_Encode_Flush(h)
+        # the EOF + last coder blocks of all S task streams in ONE round trip (CSCMI_FlushBatch == S x CSCEnc_Encode_Flush,
+        # tests/test_gpu_parity.py); round 4 flushed handle by handle here: 954 launches + waits inside the timed region
+        rc = L.CSCMI_FlushBatch(S, H)
+        if rc != 0:
+            return {"multi_stream": f"batch flush failed rc={rc}"}
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out = sum(len(w.out) for w in ws)
@@ -278,6 +281,7 @@ def multi_stream_job(lib, src, stream_counts, level, dict_size):
         results.append({"what": f"whole {src.name} ({total_size} B) as csarc -m{level} -d{dict_size >> 20}m -p{S}: {S} independent task streams, one workgroup each, 1 GPU",
                         "value": round(total / 1e6 / dt, 3), "unit": "MB/s", "seconds": round(dt, 2), "ratio": round(out / total, 4),
                         "streams": S, "batch_launches": k, "hbm_roofline_frac": round(balg * total / dt / 1e9 / HBM_PEAK_GBS, 8),
+                        "traffic": (tr := traffic_from_profile(f"m{level}_d{dict_size >> 20}m_p{S}", total))[0], "traffic_note": tr[1],
                         "sha256_of_stream_sha256s": digest, "bit_exact_vs_reference_digest": bit_exact, "decode": dec})
     return {"multi_stream": results}
 
@@ -607,10 +611,28 @@ def run_split(args, R, lib, src, level, dict_size, split, steps, warmup, with_cp
                 line["cpu_baseline"] = {"error": repr(e)[:300]}
         if exchange is not None:
             line["exchange"] = exchange
+    if S:
+        L.CSCMI_FlushBatch(S, H)
     for h in hs:
-        L.CSCEnc_Encode_Flush(h)
         L.CSCEnc_Destroy(h)
     return line
+
+
+def other_config(args, R, lib, name):
+    """The other single-GPU BASELINE.json configs under the same clock as the headline (extra `other_configs` object of the default
+    N = 1 line, never `value`): one stream of the config's corpus at its level / dictionary, 1 warm-up + 2 timed chunks, the
+    reference on one host core over a 16 MiB prefix, the GPU's stream so far checked as a prefix of the reference's."""
+    import copy
+    from csc_amd import corpus
+    cname, lvl, dct = CONFIGS[name]
+    a = copy.copy(args)
+    a.config, a.dict, a.level, a.steps, a.warmup, a.steady_steps, a.cpu_sample_mib = name, dct, None, args.other_steps, 1, 0, 16
+    line = run_single(a, R, lib, corpus.Source(cname), lvl, parse_size(dct))
+    keep = ("value", "unit", "steps", "warmup", "ms_per_step", "ratio", "data", "roofline", "counters", "cpu_baseline", "bit_exact_vs_cpu_baseline")
+    out = {k: line[k] for k in keep if k in line}
+    out["what"] = line["config"]["workload"]
+    out["config"] = {k: v for k, v in line["config"].items() if k != "workload"}
+    return out
 
 
 def cpu_baseline_tree(root, spec, level, dict_size, want_bytes=256 << 20):
@@ -731,7 +753,8 @@ def run_tree(args, R, spec):
             "bit_exact_vs_reference": None if not gold else bool(gold["sha256"] == h.hexdigest() and gold["archive_bytes"] == asize),
             "roofline": {"bound": "hbm", "achieved": round(alg_bytes(level, asize / max(1, total)) * total * args.steps / tmax / 1e9, 4), "peak": HBM_PEAK_GBS * R.world,
                          "unit": "GB/s", "frac": round(alg_bytes(level, asize / max(1, total)) * total * args.steps / tmax / 1e9 / (HBM_PEAK_GBS * R.world), 8),
-                         "traffic": None, "note": "whole job incl. host I/O: algorithmic bytes of the LZ pass / wall-clock against N x 8 TB/s; kernels: k_encode_runs_multi* (one workgroup per task stream)"},
+                         "traffic": (tr := traffic_from_profile(f"{spec}_m{level}_d{dict_size >> 20}m", total * args.steps))[0], "traffic_note": tr[1],
+                         "note": "whole job incl. host I/O: algorithmic bytes of the LZ pass / wall-clock against N x 8 TB/s; kernels: k_encode_runs_multi* (one workgroup per task stream)"},
             "cpu_baseline": None,
         }
         if not args.no_cpu_baseline:
@@ -773,6 +796,8 @@ def main():
     ap.add_argument("--workload", default="stream", choices=["stream", "tree", "tree_mid", "tree_small"],
                     help="stream: the libcsc stream workloads above (default).  tree: the many-task curve -- a seeded tree of 4096 files / 2048 extension "
                          "groups (2.1 GB) through the archiver path end to end, tasks dealt over the ranks (csc_amd/sharded.py); tree_small: 256 files (tests)")
+    ap.add_argument("--other-steps", type=int, default=2, help="extra (N = 1, default config only): timed chunks of each of the other single-GPU BASELINE configs "
+                    "(silesia -m5 -d256m, mix5 -m2 -d1024m) reported as `other_configs`; 0 = skip")
     ap.add_argument("--p8-steps", type=int, default=2, help="extra (N = 1, enwik9 only): the N > 1 workload (-p8) on this one GPU for this many steps; 0 = skip")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -792,6 +817,8 @@ def main():
     L.CSCMI_EncodeDeviceChunkBatch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.CSCMI_EncodeDeviceChunkBatch.restype = C.c_int
     L.CSCMI_GetStats.argtypes = [C.c_void_p, C.POINTER(CSCMIStats)]
+    L.CSCMI_FlushBatch.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.CSCMI_FlushBatch.restype = C.c_int
     src = corpus.Source(name)
 
     split = args.split if args.split > 0 else (8 if R.world > 1 else 0)
@@ -813,6 +840,14 @@ def main():
                         line["p8_on_one_gpu"]["cpu_baseline"] = cpu_baseline_split(src, corpus.task_slices(src.size, 8), level, dict_size, args.cpu_split_sample_mib << 20)
                     except Exception as e:          # never lose the bench line to the CPU leg
                         line["p8_on_one_gpu"]["cpu_baseline"] = {"error": repr(e)[:300]}
+            if args.other_steps > 0:
+                # BASELINE configs[2] and the configs[4] task on this GPU, same run, same clock
+                line["other_configs"] = {}
+                for oc in ("silesia", "mix5"):
+                    try:
+                        line["other_configs"][f"{CONFIGS[oc][0]}_m{CONFIGS[oc][1]}_d{CONFIGS[oc][2]}"] = other_config(args, R, lib, oc)
+                    except BaseException as e:          # never lose the headline to an extra (SystemExit included)
+                        line["other_configs"][oc] = {"error": repr(e)[:300]}
             if args.multi_streams:
                 # extra field, not `value`: every task of the -p<S> split at once on this one GPU
                 line.update(multi_stream_job(lib, src, [int(x) for x in args.multi_streams.split(",")], level, dict_size))

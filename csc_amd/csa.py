@@ -40,7 +40,7 @@ LIST_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_in
 
 SYMBOLS = ["CSA_OptionsInit", "CSA_Add", "CSA_Extract", "CSA_Test", "CSA_List", "CSA_ReadIndex",
            "CSA_Adler32", "CSAMI_Adler32Device", "CSA_DecimalTime", "CSA_UnixTime",
-           "CSAMI_AddShardEncode", "CSAMI_FreeBlob", "CSAMI_AddShardAssemble", "CSAMI_PlanInfo", "CSA_IndexRoundTrip"]
+           "CSAMI_AddShardEncode", "CSAMI_FreeBlob", "CSAMI_AddShardAssemble", "CSAMI_PlanInfo", "CSAMI_PlanShards", "CSA_IndexRoundTrip"]
 
 CSA_MAX_FRAGMENTS = 127
 CSA_TOO_MANY_FRAGMENTS = -94
@@ -146,6 +146,20 @@ def add_shard_encode(filenames: Sequence[str], rank: int, world: int, **opts):
         blob = C.string_at(ptr, ln.value)
         lib().CSAMI_FreeBlob(ptr)
     return rc, blob, st.as_dict()
+
+
+def plan_shards(filenames: Sequence[str], world: int, **opts):
+    """the deal add_shard_encode uses, without encoding anything (host only): -> (rank of every task, cost estimate of every task)"""
+    o = options(**opts)
+    arr, n = _names(filenames)
+    L = lib()
+    L.CSAMI_PlanShards.restype = C.c_int
+    nt = L.CSAMI_PlanShards(arr, n, C.byref(o), world, None, None, 0)
+    if nt < 0:
+        raise RuntimeError(f"CSAMI_PlanShards failed rc={nt}")
+    ro, co = (C.c_uint32 * max(nt, 1))(), (C.c_double * max(nt, 1))()
+    L.CSAMI_PlanShards(arr, n, C.byref(o), world, ro, co, nt)
+    return list(ro[:nt]), list(co[:nt])
 
 
 def add_shard_assemble(arcname: str, filenames: Sequence[str], blobs: Sequence[bytes], **opts):

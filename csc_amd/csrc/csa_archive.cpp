@@ -1250,7 +1250,63 @@ int CSA_Add(const char *arcname, const char *const *filenames, int nfilenames, c
     return rc;
 }
 
-// ---- sharded Add: one process per GPU, tasks dealt round-robin in dispatch order ----
+// ---- sharded Add: one process per GPU ----
+// Which rank encodes which task.  The reference's workers take the next task of the size-sorted list whenever one of them is free
+// (csarc.cpp:361-398) -- load-aware by construction.  Ranks do not talk while they encode, so every rank computes the same deal up
+// front: longest-processing-time-first over an estimated cost = bytes x a factor for the kind of data (a look at the first 8 KiB
+// of the task's first file, in the spirit of Analyzer::Analyze csc_analyzer.cpp:184-239: the level-3 kernels encode English-text-like
+// data ~2.2 x faster than binary / delta data), each task to the rank with the least cost so far (ties: lowest rank).  The deal is
+// a schedule, not data: the archive is the same whatever it is (tasks are appended in id order).  CSA_DEAL=mod restores round 3's
+// `task i -> rank i mod world`.
+double task_cost_factor(const Task &t)
+{
+    for (const FilePiece &f : t.files) {
+        if (!f.size) continue;
+        int fd = open(f.path.c_str(), O_RDONLY);
+        if (fd < 0) continue;
+        uint8_t buf[8192];
+        ssize_t n = pread(fd, buf, sizeof(buf), (off_t)f.off);
+        close(fd);
+        if (n < 512) return 1.6;
+        uint32_t hi = 0, alpha = 0, sp = 0;
+        for (ssize_t i = 0; i < n; i++) { hi += buf[i] >= 128; alpha += buf[i] >= 'a' && buf[i] <= 'z'; sp += buf[i] == ' ' || buf[i] == '\n'; }
+        const bool text = hi < (uint32_t)n / 8 && alpha > (uint32_t)n / 3 && sp > (uint32_t)n / 16;
+        return text ? 1.0 : 2.2;
+    }
+    return 1.0;
+}
+void deal_tasks(const std::vector<Task> &tasks, int world, std::vector<uint32_t> &rank_of, std::vector<double> &cost)
+{
+    const size_t nt = tasks.size();
+    rank_of.assign(nt, 0); cost.assign(nt, 0.0);
+    const char *mode = getenv("CSA_DEAL");
+    const bool mod = mode && !strcmp(mode, "mod");
+    for (size_t i = 0; i < nt; i++) cost[i] = (double)tasks[i].total * (mod ? 1.0 : task_cost_factor(tasks[i]));
+    if (mod || world <= 1) { for (size_t i = 0; i < nt; i++) rank_of[i] = (uint32_t)(i % (size_t)std::max(1, world)); return; }
+    std::vector<uint32_t> order(nt);
+    for (size_t i = 0; i < nt; i++) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    std::vector<double> load((size_t)world, 0.0);
+    for (uint32_t id : order) {
+        int best = 0;
+        for (int r = 1; r < world; r++) if (load[r] < load[best]) best = r;
+        rank_of[id] = (uint32_t)best;
+        load[best] += cost[id];
+    }
+}
+
+int CSAMI_PlanShards(const char *const *filenames, int nfilenames, const CSAOptions *opt, int world, uint32_t *rank_of, double *cost, uint32_t cap)
+{
+    if (world <= 0) return -1;
+    AddPlan P;
+    if (int prc = plan_add(P, filenames, nfilenames, opt)) return prc < 0 ? prc : -prc;
+    std::vector<uint32_t> ro;
+    std::vector<double> co;
+    deal_tasks(P.tasks, world, ro, co);
+    for (size_t i = 0; i < ro.size() && i < cap; i++) { if (rank_of) rank_of[i] = ro[i]; if (cost) cost[i] = co[i]; }
+    return (int)ro.size();
+}
+
 int CSAMI_AddShardEncode(const char *const *filenames, int nfilenames, const CSAOptions *opt, int rank, int world,
                          uint8_t **blob, uint64_t *blob_len, CSAStats *st)
 {
@@ -1263,8 +1319,11 @@ int CSAMI_AddShardEncode(const char *const *filenames, int nfilenames, const CSA
     if (int prc = plan_add(P, filenames, nfilenames, opt)) return prc;
     std::vector<Task> mine;
     std::vector<uint32_t> ids;
+    std::vector<uint32_t> rank_of;
+    std::vector<double> cost;
+    deal_tasks(P.tasks, world, rank_of, cost);
     for (size_t i = 0; i < P.tasks.size(); i++)
-        if ((int)(i % (size_t)world) == rank) { mine.push_back(P.tasks[i]); ids.push_back((uint32_t)i); }   // csarc.cpp:355: dispatch order == id order
+        if ((int)rank_of[i] == rank) { mine.push_back(P.tasks[i]); ids.push_back((uint32_t)i); }   // (id order within a rank = dispatch order, csarc.cpp:355)
     std::vector<uint8_t> out;
     put_le(out, kShardMagic, 4);
     put_le(out, P.tasks.size(), 4);

@@ -19,6 +19,7 @@ constexpr uint32_t kHT3Size = 64u * kKB;      // csc_mf.h:17
 constexpr uint32_t kMFCandLimit = 32;         // csc_mf.h:34
 constexpr uint32_t kAPLimit = 2048;           // csc_lz.h:43
 constexpr uint32_t kMaxBlocksPerChunk = 2048; // 16 MiB raw_blocksize bound / 8 KiB
+constexpr uint32_t kBtUndoBytes = 128 * 36 * 8; // EncState::bt_undo: record ring x undo entries a position x {slot, old word} (csc_kernels_bt.inc)
 
 // block types, csc_typedef.h:20-40
 enum : uint32_t {
@@ -94,7 +95,8 @@ struct EncState {
     uint32_t *ap_rep;          // [(kAPLimit+1)*4] rep distances of the parser's DP nodes
     uint8_t *rc_buf, *bc_buf;  // the two persistent csc_blocksize coder buffers
     uint8_t *inbuf;            // raw_blocksize + slack: the chunk being encoded (filters work in place)
-    uint8_t *swapbuf;          // 2*raw_blocksize + slack: filter scratch
+    uint8_t *swapbuf;          // 4*raw_blocksize + slack: filter scratch
+    uint8_t *bt_undo;          // undo log of the binary-tree inserter (csc_kernels_bt.inc: kBtRec x kBtULog x 8 bytes); null without a tree
     uint8_t *arena;            // finished blocks of the current launch (ArenaRec + payload)*
     const uint16_t *trie_next; // [300*26] word trie, csc_filters.cpp:87-111
     const uint8_t *trie_sym;   // [300]

@@ -101,8 +101,6 @@ struct HostRes {
     size_t hsize;
     uint8_t *hslab;
     uint8_t *h_in;              // lazily allocated: only CSCEnc_Encode / CSCMI_EncodeHostChunk stage input on the host
-    uint8_t *h_arena;           // lazily allocated (drain_arena): where ONE handle's coder blocks are read back to; a batch of handles reads
-    size_t h_arena_cap;         // its blocks back through the calling thread's pool instead (t_batch.pool), so a task stream of the archiver pins no 7 MiB
     hipStream_t stream;
     hipEvent_t ev[32][2];       // created on first use (host_events): a handle that is only ever driven through a batch launch records none
     hipEvent_t ev_an[2];
@@ -114,7 +112,7 @@ std::mutex g_cache_mu;
 std::vector<HostRes *> g_host_cache;
 std::vector<DevSlab> g_dev_cache;
 size_t g_dev_cache_bytes = 0;
-constexpr size_t kHostCacheMax = 4096;            // entries (a stream + ~90 KiB pinned each; + 7 MiB for those that have read blocks back alone)
+constexpr size_t kHostCacheMax = 4096;            // entries (~90 KiB pinned each; coder blocks are read back through the calling thread's buffer, thread_pinned)
 constexpr size_t kDevCacheMaxBytes = 48ull << 30;
 
 }  // namespace
@@ -163,7 +161,6 @@ void host_res_destroy(HostRes *r)
     if (!r) return;
     if (r->hslab) (void)hipHostFree(r->hslab);
     if (r->h_in) (void)hipHostFree(r->h_in);
-    if (r->h_arena) (void)hipHostFree(r->h_arena);
     for (auto &pr : r->ev) for (auto &e : pr) if (e) (void)hipEventDestroy(e);
     for (auto &e : r->ev_an) if (e) (void)hipEventDestroy(e);
     if (r->stream) pooled_stream_release(r->device, r->stream);
@@ -327,16 +324,67 @@ struct EncInstance {
         int ev_used;
     } seg;
 };
-// argument arrays of the multi-stream launch ([4 * kMaxBatch] pointer-sized words: states, run lists, run
-// counts, reset flags), one set per calling thread and device, kept for the life of the thread
-// + the pinned pool a batch reads its streams' coder blocks back through (drain_batch), and the {bytes, error} pair of every stream
+// Per-thread resources, recycled through process-wide free lists: a thread that ends hands them back (its thread_local holder's
+// destructor makes no HIP call -- it may run while the runtime shuts down), the next thread that needs one takes it over.  So
+// short-lived worker threads do not accumulate pinned memory, streams or device tables.
+//  * PinBuf: the pinned buffer coder blocks are read back through -- one handle's (drain_arena: a chunk's blocks, or the few bytes
+//    of an EOF) and a batch's (drain_batch).  Grown on demand to what is actually read (power of two, >= 256 KiB), so a
+//    CSCEnc_Encode_Flush pins no arena-sized buffer and a handle pins none at all.
+//  * BatchArgs: argument arrays of the multi-stream launch ([4 * kMaxBatch] pointer-sized words: states, run lists, run counts,
+//    reset flags), one set per calling thread and device, + the {bytes, error} pair of every stream of a batch.
+struct PinBuf { uint8_t *p = nullptr; size_t cap = 0; };
 struct BatchArgs {
     int device = -1; void **d = nullptr; void **h = nullptr; void **d2 = nullptr; void **h2 = nullptr; hipStream_t side = nullptr;
-    uint8_t *pool = nullptr; uint32_t *small = nullptr;
+    uint32_t *small = nullptr;
 };
-thread_local BatchArgs t_batch;
+std::mutex g_thread_res_mu;
+std::vector<PinBuf> g_pin_free;
+std::vector<BatchArgs> g_batch_free;
+struct ThreadRes {
+    PinBuf pin;
+    BatchArgs batch;
+    ~ThreadRes()
+    {
+        std::lock_guard<std::mutex> lk(g_thread_res_mu);
+        if (pin.p) g_pin_free.push_back(pin);
+        if (batch.d) g_batch_free.push_back(batch);
+    }
+};
+thread_local ThreadRes t_res;
+#define t_batch (t_res.batch)
 constexpr int kMaxBatch = 2048;
-constexpr size_t kBatchPool = 64ull << 20;       // >= the arena of the largest raw_blocksize (3 x 16 MiB + 1 MiB)
+constexpr size_t kBatchPool = 64ull << 20;       // most a batch reads back per wait; >= the arena of the largest raw_blocksize (3 x 16 MiB + 1 MiB)
+constexpr size_t kPinMin = 256 * 1024;
+
+// the calling thread's pinned read-back buffer, at least `need` bytes (nullptr: allocation failed)
+uint8_t *thread_pinned(size_t need)
+{
+    PinBuf &b = t_res.pin;
+    if (b.cap >= need) return b.p;
+    PinBuf take;
+    {
+        std::lock_guard<std::mutex> lk(g_thread_res_mu);
+        if (b.p) { g_pin_free.push_back(b); b = PinBuf(); }
+        size_t best = g_pin_free.size();
+        for (size_t i = 0; i < g_pin_free.size(); i++)
+            if (g_pin_free[i].cap >= need && (best == g_pin_free.size() || g_pin_free[i].cap < g_pin_free[best].cap)) best = i;
+        if (best < g_pin_free.size()) { take = g_pin_free[best]; g_pin_free.erase(g_pin_free.begin() + best); }
+        else if (g_pin_free.size() > 8) {        // nothing fits and the list is long: give the smallest back to the system
+            size_t sm = 0;
+            for (size_t i = 1; i < g_pin_free.size(); i++) if (g_pin_free[i].cap < g_pin_free[sm].cap) sm = i;
+            (void)hipHostFree(g_pin_free[sm].p);
+            g_pin_free.erase(g_pin_free.begin() + sm);
+        }
+    }
+    if (!take.p) {
+        size_t cap = kPinMin;
+        while (cap < need) cap <<= 1;
+        if (hipHostMalloc((void **)&take.p, cap, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        take.cap = cap;
+    }
+    b = take;
+    return b.p;
+}
 
 void free_device(EncInstance *e)
 {
@@ -408,18 +456,14 @@ int drain_arena(EncInstance *e, int ev_used)
     }
     uint32_t used = e->h_small[0], err = e->h_small[1];
     if (err != ERR_NONE) return report_device_error(err);
+    uint8_t *pin = nullptr;
     if (used) {
-        HostRes *r = e->res;
-        if (r->h_arena_cap < used) {    // pinned, kept with the recycled host resources; sized for the worst chunk once
-            if (r->h_arena) { (void)hipHostFree(r->h_arena); r->h_arena = nullptr; r->h_arena_cap = 0; }
-            const size_t cap = (size_t)e->h.arena_cap + 64;
-            HIPCHK(hipHostMalloc((void **)&r->h_arena, cap, hipHostMallocDefault));
-            r->h_arena_cap = cap;
-        }
-        HIPCHK(hipMemcpyAsync(r->h_arena, e->h.arena, used, hipMemcpyDeviceToHost, e->stream));
+        pin = thread_pinned(used);
+        if (!pin) { fprintf(stderr, "csc-mi355x: pinned read-back buffer of %u bytes failed\n", used); return CSCMI_DEVICE_ERROR; }
+        HIPCHK(hipMemcpyAsync(pin, e->h.arena, used, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
     }
-    return write_arena(e, e->res->h_arena, used);
+    return write_arena(e, pin, used);
 }
 
 // CSCEncoder::Compress, csc_encoder_main.cpp:85-147, with the data work on the device.
@@ -597,22 +641,32 @@ int encode_chunk(EncInstance *e, const void *src, size_t size, bool on_device)
 int batch_args_ready(int device)
 {
     if (t_batch.device == device) return 0;
-    if (t_batch.d) (void)hipFree(t_batch.d);
-    if (t_batch.h) (void)hipHostFree(t_batch.h);
-    if (t_batch.d2) (void)hipFree(t_batch.d2);
-    if (t_batch.h2) (void)hipHostFree(t_batch.h2);
-    if (t_batch.side) (void)hipStreamDestroy(t_batch.side);
-    if (t_batch.pool) (void)hipHostFree(t_batch.pool);
-    if (t_batch.small) (void)hipHostFree(t_batch.small);
-    t_batch = BatchArgs();
-    HIPCHK(hipMalloc((void **)&t_batch.d, sizeof(void *) * 4 * kMaxBatch));
-    HIPCHK(hipHostMalloc((void **)&t_batch.h, sizeof(void *) * 4 * kMaxBatch, hipHostMallocDefault));
-    HIPCHK(hipMalloc((void **)&t_batch.d2, sizeof(void *) * 4 * kMaxBatch));
-    HIPCHK(hipHostMalloc((void **)&t_batch.h2, sizeof(void *) * 4 * kMaxBatch, hipHostMallocDefault));
-    HIPCHK(hipStreamCreateWithFlags(&t_batch.side, hipStreamNonBlocking));
-    HIPCHK(hipHostMalloc((void **)&t_batch.pool, kBatchPool, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&t_batch.small, sizeof(uint32_t) * 2 * kMaxBatch, hipHostMallocDefault));
-    t_batch.device = device;
+    {
+        std::lock_guard<std::mutex> lk(g_thread_res_mu);
+        if (t_batch.d) { g_batch_free.push_back(t_batch); t_batch = BatchArgs(); }
+        for (size_t i = 0; i < g_batch_free.size(); i++)
+            if (g_batch_free[i].device == device) { t_batch = g_batch_free[i]; g_batch_free.erase(g_batch_free.begin() + i); return 0; }
+    }
+    BatchArgs b;
+    auto fail = [&](hipError_t err) {
+        fprintf(stderr, "csc-mi355x: batch tables: %s\n", hipGetErrorString(err));
+        if (b.d) (void)hipFree(b.d);
+        if (b.h) (void)hipHostFree(b.h);
+        if (b.d2) (void)hipFree(b.d2);
+        if (b.h2) (void)hipHostFree(b.h2);
+        if (b.side) (void)hipStreamDestroy(b.side);
+        if (b.small) (void)hipHostFree(b.small);
+        return CSCMI_DEVICE_ERROR;
+    };
+    hipError_t err;
+    if ((err = hipMalloc((void **)&b.d, sizeof(void *) * 4 * kMaxBatch)) != hipSuccess) return fail(err);
+    if ((err = hipHostMalloc((void **)&b.h, sizeof(void *) * 4 * kMaxBatch, hipHostMallocDefault)) != hipSuccess) return fail(err);
+    if ((err = hipMalloc((void **)&b.d2, sizeof(void *) * 4 * kMaxBatch)) != hipSuccess) return fail(err);
+    if ((err = hipHostMalloc((void **)&b.h2, sizeof(void *) * 4 * kMaxBatch, hipHostMallocDefault)) != hipSuccess) return fail(err);
+    if ((err = hipStreamCreateWithFlags(&b.side, hipStreamNonBlocking)) != hipSuccess) return fail(err);
+    if ((err = hipHostMalloc((void **)&b.small, sizeof(uint32_t) * 2 * kMaxBatch, hipHostMallocDefault)) != hipSuccess) return fail(err);
+    b.device = device;
+    t_batch = b;
     return 0;
 }
 
@@ -635,6 +689,20 @@ int drain_batch(int n, CSCEncHandle *hs, const size_t *skip, hipStream_t st)
         else if ((size_t)sm[2 * i] > kBatchPool) { fprintf(stderr, "csc-mi355x: a stream's coder blocks exceed the read-back pool\n"); rc = CSCMI_DEVICE_ERROR; }
     }
     if (rc) return rc;
+    // the pool: what this batch reads back (a round's worth at most), not a fixed 64 MiB -- a CSCMI_FlushBatch needs a few KiB
+    size_t want = 0, biggest = 0;
+    for (int i = 0; i < n; i++) {
+        if (skip && !skip[i]) continue;
+        const size_t used = sm[2 * i];
+        want += (used + 255) & ~(size_t)255;
+        if (used > biggest) biggest = used;
+    }
+    if (want > kBatchPool) want = kBatchPool;
+    if (want < biggest) want = biggest;
+    if (!want) return 0;
+    uint8_t *pool = thread_pinned(want);
+    if (!pool) { fprintf(stderr, "csc-mi355x: pinned read-back pool of %zu bytes failed\n", want); return CSCMI_DEVICE_ERROR; }
+    const size_t pool_cap = t_res.pin.cap;
     std::vector<size_t> at((size_t)n, 0);
     for (int i = 0; i < n;) {
         size_t off = 0;
@@ -642,15 +710,15 @@ int drain_batch(int n, CSCEncHandle *hs, const size_t *skip, hipStream_t st)
         for (; j < n; j++) {
             if (skip && !skip[j]) continue;
             const size_t used = sm[2 * j];
-            if (off + used > kBatchPool) break;
+            if (off + used > pool_cap) break;
             at[j] = off;
-            if (used) HIPCHK(hipMemcpyAsync(t_batch.pool + off, ((EncInstance *)hs[j])->h.arena, used, hipMemcpyDeviceToHost, st));
+            if (used) HIPCHK(hipMemcpyAsync(pool + off, ((EncInstance *)hs[j])->h.arena, used, hipMemcpyDeviceToHost, st));
             off += (used + 255) & ~(size_t)255;
         }
         HIPCHK(hipStreamSynchronize(st));
         for (int k = i; k < j; k++) {
             if (skip && !skip[k]) continue;
-            int r = write_arena((EncInstance *)hs[k], t_batch.pool + at[k], sm[2 * k]);
+            int r = write_arena((EncInstance *)hs[k], pool + at[k], sm[2 * k]);
             if (r && !rc) rc = r;
         }
         i = j;
@@ -792,6 +860,7 @@ CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *outstream, ISzA
     const size_t o_arena = dtake((size_t)h.arena_cap + 64), o_binfo = dtake(sizeof(BlockInfo) * kMaxBlocksPerChunk);
     const size_t o_dup = dtake(sizeof(uint32_t) * kMaxBlocksPerChunk);
     const size_t o_runs = dtake(sizeof(RunDesc) * (kMaxBlocksPerChunk + 2));
+    const size_t o_undo = dtake(h.bt_bits ? kBtUndoBytes : 0);          // (its own region: the filter scratch can be smaller than the log when raw_blocksize is)
     const size_t o_state = dtake(sizeof(EncState));
     e->dsize = doff;
     // ---- one pinned slab
@@ -808,6 +877,7 @@ CSCEncHandle CSCEnc_Create(const CSCProps *props, ISeqOutStream *outstream, ISzA
         uint8_t *D = (uint8_t *)e->dslab, *H = e->res->hslab;
         h.wnd = D + o_wnd; h.mfbuf = (uint32_t *)(D + o_mf); h.p_lit = (uint32_t *)(D + o_plit); h.p_delta = (uint32_t *)(D + o_pdelta);
         h.rc_buf = D + o_rc; h.bc_buf = D + o_bc; h.inbuf = D + o_in; h.swapbuf = D + o_swap; h.arena = D + o_arena;
+        h.bt_undo = h.bt_bits ? D + o_undo : nullptr;
         h.binfo = (BlockInfo *)(D + o_binfo); h.dup_flags = (uint32_t *)(D + o_dup); e->d_trie = dt.trie;
         e->d_runs = (RunDesc *)(D + o_runs); e->d_entcoef = dt.coef; e->d_state = (EncState *)(D + o_state);
         e->h_in = e->res->h_in;

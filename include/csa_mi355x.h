@@ -102,8 +102,8 @@ int CSA_Add(const char *arcname, const char *const *filenames, int nfilenames, c
 
 /* Sharded Add -- one process per GPU (the reference's counterpart is compress_mt, csarc.cpp:338-409,
  * whose worker threads each take the next task of the size-sorted list and hand their archive blocks to
- * one writer).  Every rank plans the same tasks from the same file names; rank r encodes tasks
- * r, r + world, r + 2 world ... of the dispatch order (csarc.cpp:355) on ITS GPU and returns them as one
+ * one writer).  Every rank plans the same tasks from the same file names and makes the same deal (CSAMI_PlanShards: the next
+ * task of the cost-sorted list to the least loaded rank -- what csarc.cpp:361-398 does dynamically); rank r encodes its tasks on ITS GPU and returns them as one
  * opaque blob (malloc'ed; release with CSAMI_FreeBlob).  The caller moves the blobs to the writing rank
  * (RCCL over xGMI in csc_amd/sharded.py -- the only exchange on this path) and calls CSAMI_AddShardAssemble
  * there with all of them: the archive is byte for byte the one CSA_Add / `csarc a -t1` writes.
@@ -111,6 +111,10 @@ int CSA_Add(const char *arcname, const char *const *filenames, int nfilenames, c
 int CSAMI_AddShardEncode(const char *const *filenames, int nfilenames, const CSAOptions *o, int rank, int world,
                          uint8_t **blob, uint64_t *blob_len, CSAStats *st);
 void CSAMI_FreeBlob(uint8_t *blob);
+/* The deal CSAMI_AddShardEncode uses (host only, no GPU): task i of the plan -> rank_of[i], with the cost estimate it was made from
+ * (bytes x a data-kind factor; longest-processing-time-first, deterministic on every rank; CSA_DEAL=mod in the environment: i mod
+ * world).  Fills at most `cap` entries; returns the number of tasks, or < 0. */
+int CSAMI_PlanShards(const char *const *filenames, int nfilenames, const CSAOptions *o, int world, uint32_t *rank_of, double *cost, uint32_t cap);
 int CSAMI_AddShardAssemble(const char *arcname, const char *const *filenames, int nfilenames, const CSAOptions *o,
                            const uint8_t *const *blobs, const uint64_t *blob_lens, int nblobs, CSAStats *st);
 

@@ -17,6 +17,17 @@
  *  3. find_match's ACCEPTANCE OVER A RECORD: rep candidates (the only ones that need the parse) first, then HT2 / HT3 / far head
  *     from the record with the reference's distance gating, then the descent's pairs filtered by `length > minlen`; a capped
  *     length (= good_len) is extended against the window on demand.
+ *  4. (round 5) THE HASH SIDE OF THE ACCEPTANCE DOES NOT NEED THE PARSE EITHER.  minlen only grows, and a candidate is accepted iff its
+ *     length exceeds the running minlen; so with m0 = minlen after the four rep candidates, "accepted under m0" == "accepted under
+ *     m0 = 1, and longer than m0".  The inserter therefore runs the HT2 / HT3 / far-head / descent part of find_match once with
+ *     minlen = 1 and leaves the pushed candidates H' (strictly increasing lengths) in the record; the parser's list is
+ *     [rep part] + the suffix of H' longer than m0 -- no per-candidate work.  Exactness of the caps: lengths in a record stop at
+ *     good_len.  (a) no rep reached good_len and no considered HT2 / HT3 / far candidate is capped: every comparison the reference makes
+ *     is between numbers below the cap, except for the descent's terminal pair (length == good_len, last of H'), which is extended on
+ *     demand.  (b) otherwise (`amb`, or a rep of good_len: the reference sets dist = 0xFFFFFFFF and skips HT2 / HT3): every later
+ *     candidate needs a real length above good_len, so of the descent only the terminal pair (`dcap`) can still count -- the general
+ *     walk over rep / HT2 / HT3 / far / that one pair decides.  btm_find_match_fast is this; it is asserted equal to the full
+ *     walk over the raw pairs (btm_find_match) at EVERY call.  Needs good_len > 6 (the bound[] rule must see real lengths).
  */
 #include <stdio.h>
 #include "../../oracle/orc_encoder.c"
@@ -32,13 +43,18 @@ typedef struct {
     uint32_t el[BT_MAXE], ed[BT_MAXE];
     uint32_t un;                           /* undo log: tree words this insert overwrote */
     uint32_t uslot[BT_ULOG], uold[BT_ULOG];
+    /* round 5: the hash side of find_match's acceptance, done by the inserter (point 4 of the header) */
+    uint32_t hn, hl[BT_MAXE + 3], hd[BT_MAXE + 3];   /* H': what find_match pushes from HT2 / HT3 / far head / the descent when no rep candidate counts */
+    uint32_t m3;                           /* minlen after the HT2 / HT3 / far-head stage under that assumption (capped lengths) */
+    uint32_t amb;                          /* a CONSIDERED HT2 / HT3 / far-head candidate reached the compare cap: its real length decides what follows */
+    uint32_t dcap;                         /* distance of the descent's pair that reached good_len (0 = none): the one pair whose real length can exceed its record */
 } BtRec;
 
 static struct {
     BtRec rec[BT_R];
     uint32_t sb0, pos0, btpos0, size, head;
     int la, pipe;
-    unsigned long long n_batches, n_events, n_undo_pos, n_fallback_sb, n_pipe_sb, n_samehash, n_extend, n_rounds, n_steps, n_find, n_shadow, n_blocked;
+    unsigned long long n_batches, n_events, n_undo_pos, n_fallback_sb, n_pipe_sb, n_samehash, n_extend, n_rounds, n_steps, n_find, n_shadow, n_blocked, n_fast, n_slow;
     unsigned long long h_rounds[12], h_chain[12], h_steps[12], n_chainsteps;
 } B;
 
@@ -209,6 +225,31 @@ static void btm_batch(OrcEnc *e, uint32_t i0, uint32_t n)
             cyc[k]++;
         }
     }
+    /* H' (header, point 4): find_match's walk over HT2 / HT3 / far head / pairs with minlen = 1 and no rep kill, on the capped lengths */
+    for (uint32_t k = 0; k < n; k++) {
+        BtRec *R = &B.rec[(i0 + k) % BT_R];
+        uint32_t m = 1, kill = 0;
+        R->hn = 0; R->amb = 0; R->dcap = 0;
+#define H_PUSH(L, D) do { R->hl[R->hn] = (L); R->hd[R->hn] = (D); R->hn++; } while (0)
+        if (R->d2 < e->vld_rge) {                                   /* :297-301 (dist = 0: always looked at) */
+            if (R->l2 >= e->good_len) R->amb = 1;
+            if (R->l2 > m) { m = R->l2; if (!(R->l2 <= 6 && R->d2 >= kBound[R->l2])) { H_PUSH(R->l2, R->d2); if (R->l2 >= e->good_len) kill = 1; } }
+        }
+        if (!kill && R->d3 > R->d2 && R->d3 < e->vld_rge) {         /* :334: only behind HT2's distance */
+            if (R->l3 >= e->good_len) R->amb = 1;
+            if (R->l3 > m) { m = R->l3; if (!(R->l3 <= 6 && R->d3 >= kBound[R->l3])) H_PUSH(R->l3, R->d3); }
+        }
+        if (R->dfar) {
+            if (R->lfar >= e->good_len) R->amb = 1;
+            if (R->lfar > m) { m = R->lfar; if (!(R->lfar <= 6 && R->dfar >= kBound[R->lfar])) H_PUSH(R->lfar, R->dfar); }
+        }
+        R->m3 = m;
+        for (uint32_t j = 0; j < R->n; j++) {
+            if (R->el[j] > m) H_PUSH(R->el[j], R->ed[j]);           /* (raw pairs increase strictly: a suffix) */
+            if (R->el[j] >= e->good_len) { if (j + 1 != R->n) btm_die("a capped pair that is not the terminal one"); R->dcap = R->ed[j]; }
+        }
+#undef H_PUSH
+    }
     { uint32_t b = 0; while ((1u << b) <= rounds_here && b < 11) b++; B.h_rounds[b]++; }
     for (uint32_t k = 0; k < n; k++) { uint32_t st = cyc[k], b = 0; while ((1u << b) <= st && b < 11) b++; B.h_steps[b]++; if (prevlane[k] >= 0) B.n_chainsteps += st; }
 }
@@ -322,10 +363,91 @@ static uint32_t btm_find_match(OrcEnc *e, MFUnit *ret, const uint32_t *rep_dist,
     return cnt;
 }
 
+/* the parser's side of point 4: rep candidates here, the hash side from H' */
+static uint32_t btm_find_match_fast(OrcEnc *e, MFUnit *ret, const uint32_t *rep_dist, uint32_t p)
+{
+    const uint32_t wpos = B.sb0 + p, limit = B.size - p;
+    const uint8_t *pcur = e->wnd + wpos;
+    const BtRec *R = &B.rec[p % BT_R];
+    uint32_t minlen = 1, cnt = 0, kill = 0;
+#define PUSH_CAND(L, D) do { ret[cnt].len = (L); ret[cnt].dist = (D); if (cnt + 2 < MF_CAND_LIMIT) cnt++; } while (0)
+    for (uint32_t i = 0; i < 4; i++) {
+        if (rep_dist[i] >= e->vld_rge) continue;
+        uint32_t cmp_pos = wrap_back(e, wpos, rep_dist[i]);
+        uint32_t match_len = prefix_len(pcur, e->wnd + cmp_pos, UMIN(limit, e->wnd_size - cmp_pos));
+        if (i == 0 && match_len >= 2) PUSH_CAND(1, 1);
+        if (match_len > minlen) {
+            minlen = match_len;
+            PUSH_CAND(match_len, 1 + i);
+            if (match_len >= e->good_len) { kill = 1; break; }
+        }
+    }
+    if (!kill && !R->amb) {
+        /* (a): the suffix of H' that is longer than the reps' minlen; its last entry may be the capped terminal pair */
+        B.n_fast++;
+        for (uint32_t j = 0; j < R->hn; j++) {
+            uint32_t ml = R->hl[j];
+            if (ml <= minlen) continue;
+            if (ml >= e->good_len) {
+                if (j + 1 != R->hn || R->hd[j] != R->dcap) btm_die("a capped entry of H' that is not the terminal pair");
+                uint32_t cp = wrap_back(e, wpos, R->hd[j]);
+                ml = btm_prefix_from(pcur, e->wnd + cp, e->good_len, UMIN(limit, e->wnd_size - cp));
+            }
+            PUSH_CAND(ml, 4 + R->hd[j]);
+        }
+        return cnt;
+    }
+    /* (b): the general walk over HT2 / HT3 / far head and the one pair that can still count */
+    B.n_slow++;
+    uint32_t dist = kill ? 0xFFFFFFFFu : 0;
+    for (int t = 0; t < 2; t++) {
+        const uint32_t d = t == 0 ? R->d2 : R->d3;
+        uint32_t ml = t == 0 ? R->l2 : R->l3;
+        if (!(d > dist)) continue;
+        dist = d;
+        if (d >= e->vld_rge) continue;
+        if (ml >= e->good_len) {
+            uint32_t cp = t == 0 ? (wpos > d ? wpos - d : wpos + e->wnd_size - d) : wrap_back(e, wpos, d);
+            ml = btm_prefix_from(pcur, e->wnd + cp, e->good_len, UMIN(limit, e->wnd_size - cp));
+        }
+        if (ml > minlen) {
+            minlen = ml;
+            if (ml <= 6 && d >= kBound[ml]) continue;
+            PUSH_CAND(ml, 4 + d);
+            if (ml >= e->good_len) dist = 0xFFFFFFFFu;
+        }
+    }
+    if (R->dfar) {
+        uint32_t ml = R->lfar;
+        if (ml >= e->good_len) {
+            uint32_t cp = wrap_back(e, wpos, R->dfar);
+            ml = btm_prefix_from(pcur, e->wnd + cp, e->good_len, UMIN(limit, e->wnd_size - cp));
+        }
+        if (ml > minlen) {
+            minlen = ml;
+            if (!(ml <= 6 && R->dfar >= kBound[ml])) PUSH_CAND(ml, 4 + R->dfar);
+        }
+    }
+    if (R->dcap) {
+        uint32_t cp = wrap_back(e, wpos, R->dcap);
+        uint32_t ml = btm_prefix_from(pcur, e->wnd + cp, e->good_len, UMIN(limit, e->wnd_size - cp));
+        if (ml > minlen) { minlen = ml; PUSH_CAND(ml, 4 + R->dcap); }
+    }
+#undef PUSH_CAND
+    return cnt;
+}
+
 static void btm_find_priced(OrcEnc *e, uint32_t state, MFUnit *ret, const uint32_t *rep_dist, uint32_t p)
 {
     e->mfcand[0].len = 1; e->mfcand[0].dist = 0;
     uint32_t n = btm_find_match(e, e->mfcand + 1, rep_dist, p);
+    if (e->good_len > 6) {
+        /* point 4 of the header: the record's pre-accepted hash list gives the same candidates, at every call */
+        MFUnit alt[MF_CAND_LIMIT + 2];
+        uint32_t n2 = btm_find_match_fast(e, alt, rep_dist, p);
+        if (n2 != n) btm_die("fast acceptance: candidate count differs");
+        for (uint32_t i = 0; i < n; i++) if (alt[i].len != e->mfcand[1 + i].len || alt[i].dist != e->mfcand[1 + i].dist) btm_die("fast acceptance: candidate differs");
+    }
     ret[0] = e->mfcand[n];
     if (ret[0].len >= e->good_len) return;
     ret[1].dist = 0;
@@ -446,7 +568,7 @@ __attribute__((destructor)) static void btm_stats(void)
     fprintf(stderr, "bt_model: histograms (bucket b: value < 2^b): rounds/batch"); for (int i = 0; i < 12; i++) fprintf(stderr, " %llu", B.h_rounds[i]);
     fprintf(stderr, " | longest chain/batch"); for (int i = 0; i < 12; i++) fprintf(stderr, " %llu", B.h_chain[i]);
     fprintf(stderr, " | steps/lane"); for (int i = 0; i < 12; i++) fprintf(stderr, " %llu", B.h_steps[i]);
-    fprintf(stderr, " | steps of chained lanes %llu | blocked lane-rounds %llu\n", B.n_chainsteps, B.n_blocked);
+    fprintf(stderr, " | steps of chained lanes %llu | blocked lane-rounds %llu | acceptance from H' %llu, general walk %llu\n", B.n_chainsteps, B.n_blocked, B.n_fast, B.n_slow);
 }
 __attribute__((constructor)) static void btm_install(void)
 {

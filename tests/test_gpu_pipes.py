@@ -40,6 +40,20 @@ def test_binary_tree_inserter_custom_geometry(libs, bt_size, cyc, good, dsz):
     assert prod.encode(data, props=mk(prod)) == orc.encode(data, props=mk(orc), alloc=za)
 
 
+@pytest.mark.parametrize("raw", [8192, 4096 + 512, 24576])
+def test_binary_tree_inserter_small_raw_blocksize(libs, raw):
+    """round 4's advisor finding: the inserter's undo log (36 KiB) used to live in the filter scratch (4 x raw_blocksize), so a
+    raw_blocksize below ~9 KiB let it run into the output arena.  It has a region of its own now (EncState::bt_undo)."""
+    prod, orc, za = libs
+    data = cases.build([["text", 21, 0, 150000], ["pattern", "00", 40000], ["exe", 22, 0, 60000], ["zeros", 30000]])
+
+    def mk(L):
+        p = L.props_init(1 << 20, 5)
+        p.raw_blocksize = raw
+        return p
+    assert prod.encode(data, props=mk(prod)) == orc.encode(data, props=mk(orc), alloc=za)
+
+
 HP_DATA = [["text", 13, 0, 500000], ["exe", 14, 0, 200000], ["pattern", "00", 70000], ["delta", 3, 0, 100000], ["text", 13, 0, 100000]]
 
 
