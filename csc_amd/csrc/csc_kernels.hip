@@ -738,7 +738,11 @@ DEV void hp_inserter(Sc &) {}
 DEV void hp_quit(Sc &) {}
 DEV bool bt_ok(const Sc &, uint32_t) { return false; }
 DEV void lz_compress_advanced_bt(Sc &, uint32_t) {}
-DEV void bt_init(Sc &) {}
+DEV void bt_parser_call(Sc &, uint32_t) {}
+DEV void bt_inserter_call(Sc &) {}
+DEV void bt_post_call(Sc &) {}
+DEV void bt_coder_call(Sc &) {}
+DEV void bt_init(Sc &, uint32_t) {}
 DEV void bt_inserter(Sc &) {}
 DEV void bt_post(Sc &) {}
 DEV void bt_quit(Sc &) {}
