@@ -173,6 +173,9 @@ struct Sc {
 #endif
 
 DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+// a 64-bit value / a pointer that is the same in every lane, told to the compiler (two v_readfirstlane)
+DEV uint64_t uni64(uint64_t v) { return ((uint64_t)UNI((uint32_t)(v >> 32)) << 32) | UNI((uint32_t)v); }
+template <class T> DEV T *uni_gptr(T *p) { return (T *)(uintptr_t)uni64((uint64_t)(uintptr_t)p); }
 DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 DEV uint32_t rdlane(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 // write a uniform value into one lane of a per-lane register (v_cmp + v_cndmask)
@@ -723,6 +726,7 @@ DEV void compress_rle(Sc &c, const gu8 *src, uint32_t size)
     }
 }
 
+DEV void sc_load_regs(Sc &c, EncState *S, EncLds *L);   // csc_kernels_blocks.inc: the register part of a context (the roles' own functions build theirs with it)
 #include "csc_kernels_mf.inc"
 #include "csc_kernels_lz.inc"
 #include "csc_kernels_dp2.inc"
@@ -736,6 +740,9 @@ DEV void lz_compress_normal_hp(Sc &, uint32_t, bool) {}
 DEV void hp_init(Sc &) {}
 DEV void hp_inserter(Sc &) {}
 DEV void hp_quit(Sc &) {}
+DEV void hp_parser_call(Sc &, uint32_t, bool) {}
+DEV void hp_inserter_call(Sc &) {}
+DEV void hp_coder_call(Sc &) {}
 DEV bool bt_ok(const Sc &, uint32_t) { return false; }
 DEV void lz_compress_advanced_bt(Sc &, uint32_t) {}
 DEV void bt_parser_call(Sc &, uint32_t) {}
@@ -753,6 +760,7 @@ DEV CoderQ *bt_coderq(Sc &) { return nullptr; }
 #include "csc_kernels_dp4.inc"
 #else
 DEV void lz_compress_advanced_dp4(Sc &, uint32_t) {}
+DEV void d4_master_call(Sc &, uint32_t) {}
 DEV void d4_init(Sc &) {}
 DEV void d4_worker(Sc &) {}
 DEV void d4_quit(Sc &) {}
