@@ -761,8 +761,9 @@ DEV CoderQ *bt_coderq(Sc &) { return nullptr; }
 #else
 DEV void lz_compress_advanced_dp4(Sc &, uint32_t) {}
 DEV void d4_master_call(Sc &, uint32_t) {}
-DEV void d4_init(Sc &) {}
+DEV void d4_init(Sc &, uint32_t) {}
 DEV void d4_worker(Sc &) {}
+DEV void d4_worker_call(Sc &) {}
 DEV void d4_quit(Sc &) {}
 DEV CoderQ *d4_coderq(Sc &) { return nullptr; }
 #endif

@@ -23,7 +23,7 @@ for L in libs.values():
 CH = 2 << 20
 
 
-def enc_streams(lib, datas, level, dict_size):
+def enc_streams(lib, datas, level, dict_size, batch=False):
     """-> (seconds, [stream bytes]) ; one stream: per-chunk calls; several: batch calls"""
     L = lib.lib
     hs, ws, devs = [], [], []
@@ -43,7 +43,7 @@ def enc_streams(lib, datas, level, dict_size):
         Z = [max(0, min(CH, len(d) - k * CH)) for d in datas]
         if not any(Z):
             break
-        if n == 1:
+        if n == 1 and not batch:
             assert L.CSCMI_EncodeDeviceChunk(hs[0], C.c_void_p(devs[0].data_ptr() + k * CH), Z[0]) == 0
         else:
             P = (C.c_void_p * n)(*[t.data_ptr() + k * CH for t in devs])
@@ -56,7 +56,8 @@ def enc_streams(lib, datas, level, dict_size):
     return dt, [bytes(w.out) for w in ws]
 
 
-WORK = {"m3": ("enwik9", 3, 64 << 20, 1), "p8": ("enwik9", 3, 64 << 20, 8), "m5": ("silesia.tar", 5, 256 << 20, 1), "m2": ("mix5", 2, 1 << 30, 1)}
+WORK = {"m3": ("enwik9", 3, 64 << 20, 1), "p8": ("enwik9", 3, 64 << 20, 8), "m5": ("silesia.tar", 5, 256 << 20, 1), "m2": ("mix5", 2, 1 << 30, 1),
+        "m3b": ("enwik9", 3, 64 << 20, 1), "m5b": ("silesia.tar", 5, 256 << 20, 1), "m2b": ("mix5", 2, 1 << 30, 1)}      # ..b: one stream through the batch call (the multi instance of the kernel)
 mib = int(os.environ.get("AB_MIB", "4"))
 streams_for_dec = {}
 for wk in what:
@@ -68,7 +69,7 @@ for wk in what:
     res = {n: [] for n in names}; dig = {}
     for rep in range(int(os.environ.get("AB_REPS", "3"))):
         for n in names:
-            dt, outs = enc_streams(libs[n], datas, level, dsz)
+            dt, outs = enc_streams(libs[n], datas, level, dsz, batch=wk.endswith("b"))
             res[n].append(sum(len(d) for d in datas) / 1e6 / dt)
             dig[n] = hashlib.sha256(b"".join(outs)).hexdigest()[:12]
             if wk in ("m3", "m2") and n == names[0]:
