@@ -416,7 +416,7 @@ DDEV void dlz_decode(Dc &c, uint32_t limit)
         }
         if (UNLIKELY(c.err)) { c.status = DEC_ERR_DECODE; return; }
         if (UNLIKELY(end)) break;
-        if (wr_kind == 1) { c.wnd[c.wnd_pos] = (uint8_t)wr_byte; c.wnd_pos++; }
+        if (wr_kind == 1) { if (c.lane == 0) c.wnd[c.wnd_pos] = (uint8_t)wr_byte; c.wnd_pos++; }
         else if (wr_kind == 2) {
             c.ctx = dcopy_match(c, wr_from, wr_dist, wr_len);
             c.wnd_pos += wr_len;
@@ -616,23 +616,28 @@ DDEV void decode_stream(gDecState *D, DecLds &lds)
 {
     Dc c;
     c.D = D; c.L = &lds; c.lane = threadIdx.x;
-    c.wnd = (dgu8 *)D->wnd; c.out = (dgu8 *)D->out; c.q[0] = (dgu8 *)D->q[0]; c.q[1] = (dgu8 *)D->q[1];
-    c.p_delta = (dgu32 *)D->p_delta;
-    c.qsize[0] = (dgu32 *)D->qsize[0]; c.qsize[1] = (dgu32 *)D->qsize[1];
-    c.undo_addr = (dgu32 *)D->undo_addr; c.undo_val = (dgu32 *)D->undo_val;
-    c.wnd_size = D->wnd_size; c.bsize = D->bsize; c.qslots = D->qslots;
-    for (int i = 0; i < 2; i++) { c.avail[i] = D->avail[i]; c.taken[i] = D->taken[i]; c.rd[i] = D->rd[i]; c.fill[i] = D->fill[i]; }
-    c.range = D->range; c.code = D->code; c.bc_bits = D->bc_bits; c.bc_val = D->bc_val;
-    c.state = D->state; c.ctx = D->ctx; c.wnd_pos = D->wnd_pos; c.consumed = D->consumed;
-    for (int i = 0; i < 4; i++) c.rep[i] = D->rep[i];
+    // Every field below is the same in all lanes, and the compiler is TOLD so (v_readfirstlane): a value that merely arrives by a
+    // vector load stays in a vector register, and the bit chain -- bound = (range >> 12) * p, the compare, the two selects, the
+    // renormalisation test -- then runs on the vector unit with a quarter-rate v_mul_lo_u32 and an exec-mask branch per bit
+    // (rounds 1-4: 177 cycles a binary decision).  In scalar registers it is s_mul_i32 / s_cmp / s_cselect and a scalar branch.
+    auto U64 = [](uint64_t v) { return ((uint64_t)DUNI((uint32_t)(v >> 32)) << 32) | DUNI((uint32_t)v); };
+    c.wnd = (dgu8 *)U64((uint64_t)D->wnd); c.out = (dgu8 *)U64((uint64_t)D->out); c.q[0] = (dgu8 *)U64((uint64_t)D->q[0]); c.q[1] = (dgu8 *)U64((uint64_t)D->q[1]);
+    c.p_delta = (dgu32 *)U64((uint64_t)D->p_delta);
+    c.qsize[0] = (dgu32 *)U64((uint64_t)D->qsize[0]); c.qsize[1] = (dgu32 *)U64((uint64_t)D->qsize[1]);
+    c.undo_addr = (dgu32 *)U64((uint64_t)D->undo_addr); c.undo_val = (dgu32 *)U64((uint64_t)D->undo_val);
+    c.wnd_size = DUNI(D->wnd_size); c.bsize = DUNI(D->bsize); c.qslots = DUNI(D->qslots);
+    for (int i = 0; i < 2; i++) { c.avail[i] = DUNI(D->avail[i]); c.taken[i] = DUNI(D->taken[i]); c.rd[i] = DUNI(D->rd[i]); c.fill[i] = DUNI(D->fill[i]); }
+    c.range = DUNI(D->range); c.code = DUNI(D->code); c.bc_bits = DUNI(D->bc_bits); c.bc_val = DUNI(D->bc_val);
+    c.state = DUNI(D->state); c.ctx = DUNI(D->ctx); c.wnd_pos = DUNI(D->wnd_pos); c.consumed = U64(D->consumed);
+    for (int i = 0; i < 4; i++) c.rep[i] = DUNI(D->rep[i]);
 #ifdef CSCMI_TIMERS
     for (int i = 0; i < 16; i++) c.tm[i] = 0;
     unsigned long long tk0 = __builtin_readcyclecounter();
 #endif
     c.need = 0; c.err = 0; c.undo_n = 0; c.careful = 1;
     c.bv[0] = c.bv[1] = 0; c.woff[0] = c.woff[1] = 64;
-    c.phase = D->phase; c.type = D->type; c.run_size = D->run_size; c.i = D->i; c.copied = D->copied; c.copied_from = D->copied_from;
-    c.out_size = D->out_size; c.p_delta_ready = D->p_delta_ready; c.status = DEC_RUNNING;
+    c.phase = DUNI(D->phase); c.type = DUNI(D->type); c.run_size = DUNI(D->run_size); c.i = DUNI(D->i); c.copied = DUNI(D->copied); c.copied_from = DUNI(D->copied_from);
+    c.out_size = DUNI(D->out_size); c.p_delta_ready = DUNI(D->p_delta_ready); c.status = DEC_RUNNING;
     for (uint32_t i = c.lane; i < P_COUNT; i += 64) lds.P[i] = D->probs[i];
     for (uint32_t i = c.lane; i < 122; i += 64) {
         const dgu8 *w = (const dgu8 *)D->words + i * 8;
@@ -645,7 +650,7 @@ DDEV void decode_stream(gDecState *D, DecLds &lds)
         for (uint32_t i = c.lane; i < 65536 * 2 / 16; i += 64) dst[i] = src[i];
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    const uint32_t max = D->raw_blocksize;
+    const uint32_t max = DUNI(D->raw_blocksize);
     Ck k;
     bool done = false;
     while (!done && !c.need && c.status == DEC_RUNNING) {

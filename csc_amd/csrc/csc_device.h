@@ -19,7 +19,7 @@ constexpr uint32_t kHT3Size = 64u * kKB;      // csc_mf.h:17
 constexpr uint32_t kMFCandLimit = 32;         // csc_mf.h:34
 constexpr uint32_t kAPLimit = 2048;           // csc_lz.h:43
 constexpr uint32_t kMaxBlocksPerChunk = 2048; // 16 MiB raw_blocksize bound / 8 KiB
-constexpr uint32_t kBtUndoBytes = 128 * 36 * 8; // EncState::bt_undo: record ring x undo entries a position x {slot, old word} (csc_kernels_bt.inc)
+constexpr uint32_t kBtUndoBytes = 256 * 36 * 8; // EncState::bt_undo: record ring x undo entries a position x {slot, old word} (csc_kernels_bt.inc)
 
 // block types, csc_typedef.h:20-40
 enum : uint32_t {

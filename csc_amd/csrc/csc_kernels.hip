@@ -231,8 +231,7 @@ DEV void emit_block(Sc &c, uint32_t kind, const gu8 *buf, uint32_t size)
 //   0x40000000 | nbits << 16 | value    EncDirect16
 //   0x20000000                          Coder::Flush
 // in coding order; the coder wavefront owns low / range / cache / the two block buffers and the output arena.
-// (the second code object's only user is the binary-tree form, whose two streams a CU leave 2 KiB for it)
-constexpr uint32_t kCoderQ = CSCMI_TU == 2 ? 512 : 4096;
+constexpr uint32_t kCoderQ = 4096;
 struct CoderQ {
     uint32_t pub, tail, done, pad;
     uint32_t e[kCoderQ];
