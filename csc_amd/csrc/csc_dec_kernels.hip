@@ -104,7 +104,7 @@ DDEV void ck_rollback(Dc &c, const Ck &k)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     c.undo_n = 0;
     for (int i = 0; i < 2; i++) { c.taken[i] = k.taken[i]; c.rd[i] = k.rd[i]; c.fill[i] = k.fill[i]; c.woff[i] = 64; }
-    c.range = k.range; c.code = k.code; c.bc_bits = k.bc_bits; c.bc_val = k.bc_val;
+    c.range = DUNI(k.range); c.code = DUNI(k.code); c.bc_bits = k.bc_bits; c.bc_val = k.bc_val;
     c.state = k.state; c.ctx = k.ctx; c.wnd_pos = k.wnd_pos; c.consumed = k.consumed;
     for (int i = 0; i < 4; i++) c.rep[i] = k.rep[i];
 }
@@ -145,14 +145,52 @@ DDEV uint32_t next_byte(Dc &c, int kind)
 // lanes that hold those nodes: one vector update + one LDS store per tree instead of one per bit (tree_update).
 DDEV uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 
-DDEV uint32_t rc_bit(Dc &c, uint32_t p)
+// range / code into scalar registers: at the top of every packet (what flows around the packet loop may count as per-lane data)
+DDEV void rc_scalar(Dc &c) { c.range = DUNI(c.range); c.code = DUNI(c.code); }
+template <int SITE>
+DDEV uint32_t rc_bit_at(Dc &c, uint32_t p)
 {
-    if (UNLIKELY(c.range < (1u << 24))) { c.range <<= 8; c.code = (c.code << 8) + next_byte(c, 1); }
-    const uint32_t bound = (c.range >> 12) * p;
-    const bool one = c.code < bound;
-    c.range = one ? bound : c.range - bound;
-    c.code = one ? c.code : c.code - bound;
-    return one ? 1u : 0u;
+    if (UNLIKELY(c.range < (1u << 24))) { c.range = DUNI(c.range << 8); c.code = DUNI((c.code << 8) + next_byte(c, 1)); }
+    // The chain as SCALAR instructions, spelled out: left to itself the compiler keeps range / code / the tree index in vector
+    // registers (a quarter-rate v_mul_lo_u32, v_cmp + v_cndmask pairs, a v_readfirstlane before every v_readlane: rounds 1-4
+    // measured 177 cycles a binary decision).  Eight SALU operations: bound, the two differences, one compare, three selects.
+    uint32_t bound, bit, r2, c2;
+    asm("; rc_bit site %7\n\t"
+        "s_lshr_b32 %0, %4, 12\n\t"
+        "s_mul_i32 %0, %0, %6\n\t"
+        "s_sub_u32 %2, %4, %0\n\t"
+        "s_sub_u32 %3, %5, %0\n\t"
+        "s_cmp_lt_u32 %5, %0\n\t"
+        "s_cselect_b32 %2, %0, %2\n\t"
+        "s_cselect_b32 %3, %5, %3\n\t"
+        "s_cselect_b32 %1, 1, 0"
+        : "=&s"(bound), "=&s"(bit), "=&s"(r2), "=&s"(c2)
+        : "s"(c.range), "s"(c.code), "s"(p), "n"(SITE)
+        : "scc");
+    c.range = r2;
+    c.code = c2;
+    return bit;
+}
+#define rc_bit(c, p) rc_bit_at<__LINE__>((c), (p))
+// one level of a binary tree walk: the node index moves on to 2 v + bit -- s_addc_u32 v, v, v takes the bit straight from SCC
+DDEV uint32_t rc_step(Dc &c, uint32_t p, uint32_t v)
+{
+    if (UNLIKELY(c.range < (1u << 24))) { c.range = DUNI(c.range << 8); c.code = DUNI((c.code << 8) + next_byte(c, 1)); }
+    uint32_t bound, vn, r2, c2;
+    asm("s_lshr_b32 %0, %4, 12\n\t"
+        "s_mul_i32 %0, %0, %6\n\t"
+        "s_sub_u32 %2, %4, %0\n\t"
+        "s_sub_u32 %3, %5, %0\n\t"
+        "s_cmp_lt_u32 %5, %0\n\t"
+        "s_cselect_b32 %2, %0, %2\n\t"
+        "s_cselect_b32 %3, %5, %3\n\t"
+        "s_addc_u32 %1, %7, %7"
+        : "=&s"(bound), "=&s"(vn), "=&s"(r2), "=&s"(c2)
+        : "s"(c.range), "s"(c.code), "s"(p), "s"(v)
+        : "scc");
+    c.range = r2;
+    c.code = c2;
+    return vn;
 }
 // p += (0xFFF - p) >> 5 or p -= p >> 5; 0xFFF - p == p ^ 0xFFF for 12-bit p
 DDEV uint32_t p_update(uint32_t p, uint32_t bit)
@@ -190,15 +228,17 @@ DDEV void tree_update(Dc &c, uint32_t g, uint32_t v, uint32_t node, uint32_t idx
     c.undo_n += NB;
 }
 // one stand-alone bit under a small-table probability (packet flags, length-slot bits, the long-length escape)
-DDEV uint32_t dbit_p(Dc &c, uint32_t idx, uint32_t p)
+template <int SITE>
+DDEV uint32_t dbit_p_at(Dc &c, uint32_t idx, uint32_t p)
 {
-    const uint32_t bit = rc_bit(c, p);
+    const uint32_t bit = rc_bit_at<SITE>(c, p);
     if (UNLIKELY(c.careful)) journal_put(c, c.undo_n, idx, p);
     c.undo_n++;
     c.L->P[idx] = p_update(p, bit);
     return bit;
 }
-DDEV uint32_t dbit(Dc &c, uint32_t idx) { return dbit_p(c, idx, DUNI(c.L->P[idx])); }
+#define dbit_p(c, idx, p) dbit_p_at<__LINE__>((c), (idx), (p))
+#define dbit(c, idx) dbit_p_at<__LINE__>((c), (idx), DUNI((c).L->P[(idx)]))
 
 DDEV uint32_t ddirect16(Dc &c, uint32_t len)   // coder_decode_direct, csc_dec.cpp:65-88
 {
@@ -225,7 +265,7 @@ DDEV uint32_t dbyte_tree_from(Dc &c, uint32_t row, uint32_t top)
     const uint32_t L = c.lane & 15;
     uint32_t v = 1;
 #pragma unroll
-    for (int k = 0; k < 4; k++) v = v + v + rc_bit(c, rl(top, v));
+    for (int k = 0; k < 4; k++) v = rc_step(c, rl(top, v), v);
     // subtree under node v (16..31): lane L = 2^j + t  ->  node (v << j) + t
     const uint32_t j = 31u - (uint32_t)__builtin_clz(L | 1u);
     const uint32_t sidx = row + (v << j) + (L - (1u << j));
@@ -233,7 +273,7 @@ DDEV uint32_t dbyte_tree_from(Dc &c, uint32_t row, uint32_t top)
     tree_update<4, SPACE>(c, top, v, c.lane < 16 ? L : 0u, row + L);
     uint32_t h = 1;
 #pragma unroll
-    for (int k = 0; k < 4; k++) h = h + h + rc_bit(c, rl(sub, h));
+    for (int k = 0; k < 4; k++) h = rc_step(c, rl(sub, h), h);
     tree_update<4, SPACE>(c, sub, h, c.lane < 16 ? L : 0u, sidx);
     return ((v << 4) | (h & 15u)) & 0xFF;
 }
@@ -246,17 +286,18 @@ DDEV uint32_t dmatchlen_1(Dc &c)
 {
     const uint32_t i0 = P_LEN_SLOT + c.lane, i1 = P_LEN_SLOT + 64 + c.lane, i2 = P_LEN_SLOT + 128 + (c.lane & 31);
     const uint32_t g0 = c.L->P[i0], g1 = c.L->P[i1], g2 = c.L->P[i2];
+    rc_scalar(c);          // (this bit follows joins of the packet's control flow: see rc_scalar)
     if (dbit_p(c, P_LEN_SLOT, rl(g0, 0)) == 0) {                              // 3-bit tree, lengths 0..7
         uint32_t i = 1;
 #pragma unroll
-        for (int k = 0; k < 3; k++) i = i + i + rc_bit(c, rl(g0, (P_LEN_X1 - P_LEN_SLOT) + i));
+        for (int k = 0; k < 3; k++) i = rc_step(c, rl(g0, (P_LEN_X1 - P_LEN_SLOT) + i), i);
         tree_update<3, 0>(c, g0, i, i0 - P_LEN_X1, i0);
         return i & 7u;
     }
     if (dbit_p(c, P_LEN_SLOT + 1, rl(g0, 1)) == 0) {                          // 3-bit tree, lengths 8..15
         uint32_t i = 1;
 #pragma unroll
-        for (int k = 0; k < 3; k++) i = i + i + rc_bit(c, rl(g0, (P_LEN_X2 - P_LEN_SLOT) + i));
+        for (int k = 0; k < 3; k++) i = rc_step(c, rl(g0, (P_LEN_X2 - P_LEN_SLOT) + i), i);
         tree_update<3, 0>(c, g0, i, i0 - P_LEN_X2, i0);
         return 8u + (i & 7u);
     }
@@ -265,7 +306,7 @@ DDEV uint32_t dmatchlen_1(Dc &c)
     for (int k = 0; k < 7; k++) {
         const uint32_t o = (P_LEN_X3 - P_LEN_SLOT) + i;                       // 19 .. 145
         const uint32_t p = o < 64 ? rl(g0, o) : (o < 128 ? rl(g1, o - 64) : rl(g2, o - 128));
-        i = i + i + rc_bit(c, p);
+        i = rc_step(c, p, i);
     }
     // the 7 path nodes live in up to three registers; every lane checks its own node in each (undo_n advances once)
     {
@@ -280,7 +321,9 @@ DDEV uint32_t dmatchlen_2(Dc &c)               // csc_dec.cpp:222-234
 {
     uint32_t len = dmatchlen_1(c);
     if (LIKELY(len != 143)) return len;
-    while (!c.need && !c.err && !dbit(c, P_LONGLEN)) {
+    for (;;) {
+        rc_scalar(c);          // (what flows around this loop counts as per-lane data otherwise)
+        if (c.need || c.err || dbit(c, P_LONGLEN)) break;
         len += 143;
         if (c.undo_n > kDecUndoCap) c.err = 1;   // a packet longer than any the encoder can produce
     }
@@ -298,12 +341,12 @@ DDEV void dmatch(Dc &c, uint32_t &dist, uint32_t &len)   // decode_match, csc_de
     const uint32_t gs = c.L->P[si];                                           // the whole slot tree (<= 31 nodes)
     uint32_t i = 1;
 #pragma unroll
-    for (int k = 0; k < 3; k++) i = i + i + rc_bit(c, rl(gs, i));
+    for (int k = 0; k < 3; k++) i = rc_step(c, rl(gs, i), i);
     if (sbits == 3) tree_update<3, 0>(c, gs, i, c.lane < 32 ? c.lane : 0u, si);
-    else if (sbits == 4) { i = i + i + rc_bit(c, rl(gs, i)); tree_update<4, 0>(c, gs, i, c.lane < 32 ? c.lane : 0u, si); }
+    else if (sbits == 4) { i = rc_step(c, rl(gs, i), i); tree_update<4, 0>(c, gs, i, c.lane < 32 ? c.lane : 0u, si); }
     else {
-        i = i + i + rc_bit(c, rl(gs, i));
-        i = i + i + rc_bit(c, rl(gs, i));
+        i = rc_step(c, rl(gs, i), i);
+        i = rc_step(c, rl(gs, i), i);
         tree_update<5, 0>(c, gs, i, c.lane < 32 ? c.lane : 0u, si);
     }
     uint32_t slot = i & ((1u << sbits) - 1);
@@ -314,8 +357,9 @@ DDEV void dmatch(Dc &c, uint32_t &dist, uint32_t &len)   // decode_match, csc_de
         const uint32_t ge = c.L->P[ei];                                       // the 15 nodes of the low-bits tree
         const uint32_t elen = ebits > 4 ? ddirect(c, ebits - 4) : 0;
         i = 1;
+        rc_scalar(c);
 #pragma unroll
-        for (int k = 0; k < 4; k++) i = i + i + rc_bit(c, rl(ge, i));
+        for (int k = 0; k < 4; k++) i = rc_step(c, rl(ge, i), i);
         tree_update<4, 0>(c, ge, i, c.lane < 16 ? c.lane : 0u, ei);
         dist = ((1u << ebits) + 1) + (elen << 4) + (__brev(i & 0x0Fu) >> 28);   // dist_table_[slot] + ... + rev16_table_
     }
@@ -356,6 +400,7 @@ DDEV void dlz_decode(Dc &c, uint32_t limit)
         // else -- 93 % of a 64 KiB block -- a packet cannot exhaust its block before the kDecUndoCap-bit limit stops it.
         c.careful = (c.rd[1] + kDecUndoCap / 8 + 64 > c.fill[1] || c.rd[0] + 16 > c.fill[0]) ? 1u : 0u;
         c.undo_n = 0;
+        rc_scalar(c);
         if (UNLIKELY(c.careful)) ck_take(c, k);
         uint32_t ni = i;
         bool end = false;
@@ -605,9 +650,9 @@ DDEV bool dprime(Dc &c)
         c.taken[kind]++;
         c.rd[kind] = 0;
     }
-    c.range = 0xFFFFFFFFu; c.bc_bits = c.bc_val = 0;
+    c.range = DUNI(0xFFFFFFFFu); c.bc_bits = c.bc_val = 0;
     const dgu8 *p = c.q[1] + (size_t)((c.taken[1] - 1) % c.qslots) * c.bsize;
-    c.code = (DUNI((uint32_t)p[1]) << 24) | (DUNI((uint32_t)p[2]) << 16) | (DUNI((uint32_t)p[3]) << 8) | DUNI((uint32_t)p[4]);
+    c.code = DUNI((DUNI((uint32_t)p[1]) << 24) | (DUNI((uint32_t)p[2]) << 16) | (DUNI((uint32_t)p[3]) << 8) | DUNI((uint32_t)p[4]));
     c.rd[1] = 5;
     return true;
 }
@@ -689,6 +734,7 @@ DDEV void decode_stream(gDecState *D, DecLds &lds)
                 c.p_delta_ready = 1;
             }
             while (i < size) {
+                rc_scalar(c);
                 ck_take(c, k);
                 uint32_t ni = i + 1, byte = 0, runlen = 0;
                 if (type == DT_BAD) byte = ddirect16(c, 8);
