@@ -26,6 +26,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/csc_mi355x.h"
@@ -409,29 +410,37 @@ struct Slot {
     int task = -1;
     CSCEncHandle h = nullptr;
     BlockSink *sink = nullptr;
-    uint8_t *d_chunk = nullptr;
+    uint8_t *d_chunk = nullptr, *d_chunk2 = nullptr;   // the chunk being encoded / the one the read-ahead fills meanwhile
     // reader cursor (AsyncFileReader, csa_io.h:215-272)
     size_t fi = 0;
     uint64_t fprog = 0, cum = 0;
     int fd = -1;
     uint64_t mem = 0;
+    int64_t pre_n = -1;          // >= 0: the next chunk is already in d_chunk2 (that many bytes); < -1: the read-ahead failed with that code
 };
 
-struct AddJob {
-    std::vector<Task> *tasks = nullptr;
+// What one thread needs to read chunks: a HIP stream, a ring of pinned staging buffers, the adler pieces of what it has read.
+// Lane 0 is the caller's; lane 1 belongs to the read-ahead thread that runs while the caller sits in the batch encode call --
+// the reference's reader thread per worker (csa_io.h:215-272), here one for all streams of the job.
+struct FillLane {
     hipStream_t st = nullptr;
     uint8_t *stage[kStageBufs] = {nullptr};
     hipEvent_t stage_ev[kStageBufs] = {nullptr};
     bool stage_used[kStageBufs] = {false};
     int stage_next = 0;
-    uint32_t raw_blocksize = 2u << 20;
     std::vector<AdlerPieceH> pieces;
     std::vector<PieceRef> refs;
     void *d_pieces = nullptr, *d_sums = nullptr;
     AdlerSumsH *h_sums = nullptr;
     size_t piece_cap = 0;
     uint64_t raw_bytes = 0;
-    std::vector<uint8_t *> chunk_groups;          // the slots' device chunks, kChunkGroup slots per allocation
+};
+
+struct AddJob {
+    std::vector<Task> *tasks = nullptr;
+    FillLane lane[2];
+    uint32_t raw_blocksize = 2u << 20;
+    std::vector<uint8_t *> chunk_groups;          // the slots' device chunks, kChunkGroup slots (x 2 buffers) per allocation
 };
 constexpr size_t kChunkGroup = 64;
 
@@ -440,7 +449,7 @@ constexpr size_t kChunkGroup = 64;
 // Fill the slot's device chunk with the next <= raw_blocksize bytes of its task (files back to back, what
 // AsyncReader::Read hands CSCEnc_Encode: full chunks until the task ends, csa_io.h:66-96) and queue the
 // adler pieces of every fragment part in it.  Returns the chunk size, or < 0.
-int64_t fill_chunk(AddJob &J, uint32_t slot_idx, Slot &s)
+int64_t fill_chunk(AddJob &J, FillLane &Ln, uint32_t slot_idx, Slot &s, uint8_t *d_dst)
 {
     Task &t = (*J.tasks)[s.task];
     uint64_t filled = 0;
@@ -457,9 +466,9 @@ int64_t fill_chunk(AddJob &J, uint32_t slot_idx, Slot &s)
         if (s.fprog == f.size) { close(s.fd); s.fd = -1; s.fi++; continue; }   // csa_io.h:266-270 (also empty files)
         if (filled == J.raw_blocksize) break;
         if (!stage) {
-            sb = J.stage_next; J.stage_next = (J.stage_next + 1) % kStageBufs;
-            if (J.stage_used[sb] && !HIP_OK(hipEventSynchronize(J.stage_ev[sb]))) return CSCMI_DEVICE_ERROR;
-            stage = J.stage[sb];
+            sb = Ln.stage_next; Ln.stage_next = (Ln.stage_next + 1) % kStageBufs;
+            if (Ln.stage_used[sb] && !HIP_OK(hipEventSynchronize(Ln.stage_ev[sb]))) return CSCMI_DEVICE_ERROR;
+            stage = Ln.stage[sb];
         }
         uint64_t want = std::min<uint64_t>(f.size - s.fprog, J.raw_blocksize - filled);
         uint64_t got = 0;
@@ -474,47 +483,47 @@ int64_t fill_chunk(AddJob &J, uint32_t slot_idx, Slot &s)
         }
         for (uint64_t o = 0; o < got; o += kAdlerPiece) {
             uint32_t n = (uint32_t)std::min<uint64_t>(kAdlerPiece, got - o);
-            J.pieces.push_back(AdlerPieceH{s.d_chunk + filled + o, n, 0});
-            J.refs.push_back(PieceRef{slot_idx, (uint32_t)s.fi, n});
+            Ln.pieces.push_back(AdlerPieceH{d_dst + filled + o, n, 0});
+            Ln.refs.push_back(PieceRef{slot_idx, (uint32_t)s.fi, n});
         }
         filled += got; s.fprog += got; s.cum += got;
     }
     if (filled) {
-        if (!HIP_OK(hipMemcpyAsync(s.d_chunk, stage, filled, hipMemcpyHostToDevice, J.st))) return CSCMI_DEVICE_ERROR;
-        if (!HIP_OK(hipEventRecord(J.stage_ev[sb], J.st))) return CSCMI_DEVICE_ERROR;
-        J.stage_used[sb] = true;
-        J.raw_bytes += filled;
+        if (!HIP_OK(hipMemcpyAsync(d_dst, stage, filled, hipMemcpyHostToDevice, Ln.st))) return CSCMI_DEVICE_ERROR;
+        if (!HIP_OK(hipEventRecord(Ln.stage_ev[sb], Ln.st))) return CSCMI_DEVICE_ERROR;
+        Ln.stage_used[sb] = true;
+        Ln.raw_bytes += filled;
     }
     return (int64_t)filled;
 }
 
-int run_adler(AddJob &J, std::vector<Slot> &slots)
+int run_adler(AddJob &J, FillLane &Ln, std::vector<Slot> &slots)
 {
-    size_t n = J.pieces.size();
-    if (!n) return 0;
-    if (n > J.piece_cap) {
+    size_t n = Ln.pieces.size();
+    if (!n) return HIP_OK(hipStreamSynchronize(Ln.st)) ? 0 : CSCMI_DEVICE_ERROR;      // (still: the lane's uploads must have landed)
+    if (n > Ln.piece_cap) {
         size_t cap = std::max<size_t>(n * 2, 4096);
-        if (J.d_pieces) (void)hipFree(J.d_pieces);
-        if (J.d_sums) (void)hipFree(J.d_sums);
-        if (J.h_sums) (void)hipHostFree(J.h_sums);
-        J.d_pieces = J.d_sums = nullptr; J.h_sums = nullptr;
-        if (!HIP_OK(hipMalloc(&J.d_pieces, cap * sizeof(AdlerPieceH))) || !HIP_OK(hipMalloc(&J.d_sums, cap * sizeof(AdlerSumsH)))
-            || !HIP_OK(hipHostMalloc((void **)&J.h_sums, cap * sizeof(AdlerSumsH), hipHostMallocDefault)))
+        if (Ln.d_pieces) (void)hipFree(Ln.d_pieces);
+        if (Ln.d_sums) (void)hipFree(Ln.d_sums);
+        if (Ln.h_sums) (void)hipHostFree(Ln.h_sums);
+        Ln.d_pieces = Ln.d_sums = nullptr; Ln.h_sums = nullptr;
+        if (!HIP_OK(hipMalloc(&Ln.d_pieces, cap * sizeof(AdlerPieceH))) || !HIP_OK(hipMalloc(&Ln.d_sums, cap * sizeof(AdlerSumsH)))
+            || !HIP_OK(hipHostMalloc((void **)&Ln.h_sums, cap * sizeof(AdlerSumsH), hipHostMallocDefault)))
             return CSCMI_DEVICE_ERROR;
-        J.piece_cap = cap;
+        Ln.piece_cap = cap;
     }
-    if (!HIP_OK(hipMemcpyAsync(J.d_pieces, J.pieces.data(), n * sizeof(AdlerPieceH), hipMemcpyHostToDevice, J.st))) return CSCMI_DEVICE_ERROR;
-    launch_adler_pieces(J.d_pieces, J.d_sums, (uint32_t)n, J.st);
+    if (!HIP_OK(hipMemcpyAsync(Ln.d_pieces, Ln.pieces.data(), n * sizeof(AdlerPieceH), hipMemcpyHostToDevice, Ln.st))) return CSCMI_DEVICE_ERROR;
+    launch_adler_pieces(Ln.d_pieces, Ln.d_sums, (uint32_t)n, Ln.st);
     if (!HIP_OK(hipGetLastError())) return CSCMI_DEVICE_ERROR;
-    if (!HIP_OK(hipMemcpyAsync(J.h_sums, J.d_sums, n * sizeof(AdlerSumsH), hipMemcpyDeviceToHost, J.st))) return CSCMI_DEVICE_ERROR;
-    if (!HIP_OK(hipStreamSynchronize(J.st))) return CSCMI_DEVICE_ERROR;
+    if (!HIP_OK(hipMemcpyAsync(Ln.h_sums, Ln.d_sums, n * sizeof(AdlerSumsH), hipMemcpyDeviceToHost, Ln.st))) return CSCMI_DEVICE_ERROR;
+    if (!HIP_OK(hipStreamSynchronize(Ln.st))) return CSCMI_DEVICE_ERROR;
     for (size_t i = 0; i < n; i++) {
-        const PieceRef &r = J.refs[i];
+        const PieceRef &r = Ln.refs[i];
         FilePiece &f = (*J.tasks)[slots[r.slot].task].files[r.file];
-        adler_fold(f.checksum, J.h_sums[i].a, J.h_sums[i].b, r.len);       // csa_io.h:250, piecewise
+        adler_fold(f.checksum, Ln.h_sums[i].a, Ln.h_sums[i].b, r.len);       // csa_io.h:250, piecewise
     }
-    J.pieces.clear();
-    J.refs.clear();
+    Ln.pieces.clear();
+    Ln.refs.clear();
     return 0;
 }
 
@@ -526,16 +535,18 @@ void free_job(AddJob &J, std::vector<Slot> &slots)
         delete s.sink;
         s = Slot();
     }
-    for (int i = 0; i < kStageBufs; i++) {
-        if (J.stage[i]) (void)hipHostFree(J.stage[i]);
-        if (J.stage_ev[i]) (void)hipEventDestroy(J.stage_ev[i]);
-        J.stage[i] = nullptr; J.stage_ev[i] = nullptr;
+    for (FillLane &Ln : J.lane) {
+        for (int i = 0; i < kStageBufs; i++) {
+            if (Ln.stage[i]) (void)hipHostFree(Ln.stage[i]);
+            if (Ln.stage_ev[i]) (void)hipEventDestroy(Ln.stage_ev[i]);
+            Ln.stage[i] = nullptr; Ln.stage_ev[i] = nullptr;
+        }
+        if (Ln.d_pieces) (void)hipFree(Ln.d_pieces);
+        if (Ln.d_sums) (void)hipFree(Ln.d_sums);
+        if (Ln.h_sums) (void)hipHostFree(Ln.h_sums);
+        if (Ln.st) (void)hipStreamDestroy(Ln.st);
     }
     for (uint8_t *g : J.chunk_groups) (void)hipFree(g);
-    if (J.d_pieces) (void)hipFree(J.d_pieces);
-    if (J.d_sums) (void)hipFree(J.d_sums);
-    if (J.h_sums) (void)hipHostFree(J.h_sums);
-    if (J.st) (void)hipStreamDestroy(J.st);
     J = AddJob();
 }
 
@@ -571,10 +582,18 @@ int encode_tasks(std::vector<Task> &tasks, const EmitFn &emit, const CSAOptions 
     if (max_streams > kMaxStreams) max_streams = kMaxStreams;
     uint64_t mem_used = 0;
 
-    bool ok = HIP_OK(hipStreamCreateWithFlags(&J.st, hipStreamNonBlocking));
-    for (int i = 0; ok && i < kStageBufs; i++)
-        ok = HIP_OK(hipHostMalloc((void **)&J.stage[i], J.raw_blocksize, hipHostMallocDefault)) && HIP_OK(hipEventCreate(&J.stage_ev[i]));
+    bool ok = true;
+    for (FillLane &Ln : J.lane) {
+        ok = ok && HIP_OK(hipStreamCreateWithFlags(&Ln.st, hipStreamNonBlocking));
+        for (int i = 0; ok && i < kStageBufs; i++)
+            ok = HIP_OK(hipHostMalloc((void **)&Ln.stage[i], J.raw_blocksize, hipHostMallocDefault)) && HIP_OK(hipEventCreate(&Ln.stage_ev[i]));
+    }
     if (!ok) { free_job(J, slots); return CSCMI_DEVICE_ERROR; }
+    int device = 0;
+    (void)hipGetDevice(&device);
+    // CSA_READAHEAD=0 (diagnostics): every chunk is read by the calling thread between two encode calls, as in rounds 1-4
+    static const bool readahead = [] { const char *e = getenv("CSA_READAHEAD"); return !(e && atoi(e) == 0); }();
+    std::vector<uint8_t> fin;
 
     std::vector<CSCEncHandle> hs;
     std::vector<const void *> ptrs;
@@ -612,10 +631,11 @@ int encode_tasks(std::vector<Task> &tasks, const EmitFn &emit, const CSAOptions 
                 const size_t stride = ((size_t)J.raw_blocksize + 64 + 255) & ~(size_t)255;
                 if (free_slot / kChunkGroup >= J.chunk_groups.size()) {
                     uint8_t *g = nullptr;
-                    if (!HIP_OK(hipMalloc((void **)&g, stride * kChunkGroup))) { rc = CSCMI_DEVICE_ERROR; break; }
+                    if (!HIP_OK(hipMalloc((void **)&g, stride * kChunkGroup * 2))) { rc = CSCMI_DEVICE_ERROR; break; }
                     J.chunk_groups.push_back(g);
                 }
-                s.d_chunk = J.chunk_groups[free_slot / kChunkGroup] + (free_slot % kChunkGroup) * stride;
+                s.d_chunk = J.chunk_groups[free_slot / kChunkGroup] + (free_slot % kChunkGroup) * 2 * stride;
+                s.d_chunk2 = s.d_chunk + stride;
             }
             s.sink = new BlockSink();
             s.h = CSCEnc_Create(&p, &s.sink->os, NULL);
@@ -623,7 +643,7 @@ int encode_tasks(std::vector<Task> &tasks, const EmitFn &emit, const CSAOptions 
             uint8_t hdr[CSC_PROP_SIZE];
             CSCEnc_WriteProperties(&p, hdr, 0);
             s.sink->put(hdr, CSC_PROP_SIZE);                               // csa_worker.cpp:38-42
-            s.task = (int)next_admit; s.fi = 0; s.fprog = 0; s.cum = 0; s.fd = -1; s.mem = mem;
+            s.task = (int)next_admit; s.fi = 0; s.fprog = 0; s.cum = 0; s.fd = -1; s.mem = mem; s.pre_n = -1;
             mem_used += mem;
             next_admit++;
             if (st) st->peak_streams = std::max<uint32_t>(st->peak_streams, (uint32_t)active + 1);
@@ -631,27 +651,54 @@ int encode_tasks(std::vector<Task> &tasks, const EmitFn &emit, const CSAOptions 
         if (rc) break;
         if (st) st->seconds_setup += now_s() - ts;
 
-        // ---- one chunk per live stream: read, upload, adler32
+        // ---- one chunk per live stream: the one the read-ahead brought in during the last encode call, or read + upload now
+        // (a stream's first chunk); adler32 of both lanes' pieces (lane 1's are the ones of the chunks swapped in here)
         ts = now_s();
         hs.clear(); ptrs.clear(); sizes.clear(); live.clear();
+        bool any_pre = false;
         for (size_t i = 0; i < slots.size(); i++) {
             Slot &s = slots[i];
             if (s.task < 0) continue;
-            int64_t n = fill_chunk(J, (uint32_t)i, s);
+            int64_t n;
+            if (s.pre_n != -1) {
+                n = s.pre_n; s.pre_n = -1;
+                if (n >= 0) { std::swap(s.d_chunk, s.d_chunk2); any_pre = true; }
+            } else n = fill_chunk(J, J.lane[0], (uint32_t)i, s, s.d_chunk);
             if (n < 0) { rc = (int)n; break; }
             live.push_back((uint32_t)i);
             if (n) { hs.push_back(s.h); ptrs.push_back(s.d_chunk); sizes.push_back((size_t)n); }
         }
         if (rc) break;
         if (live.empty()) break;
-        rc = run_adler(J, slots);                                           // also waits for the uploads
+        rc = run_adler(J, J.lane[0], slots);                                // also waits for the uploads
+        if (rc == 0 && any_pre) rc = run_adler(J, J.lane[1], slots);
         if (rc) break;
         if (st) st->seconds_io += now_s() - ts;
+        // which streams end with this chunk: decided HERE -- the read-ahead below moves the cursors of the others on
+        fin.assign(slots.size(), 0);
+        for (uint32_t i : live) fin[i] = slots[i].fi >= tasks[slots[i].task].files.size() ? 1 : 0;
 
-        // ---- advance every stream by its chunk with one launch per parser flavour
+        // ---- advance every stream by its chunk with one launch per parser flavour; meanwhile a second thread reads the NEXT
+        // chunk of every stream that goes on into the slots' other buffers (csa_io.h:215-272: the reference's reader thread)
         if (!hs.empty()) {
             double t0 = now_s();
+            std::thread reader;
+            bool more = false;
+            for (uint32_t i : live) more = more || !fin[i];
+            if (readahead && more) {
+                reader = std::thread([&]() {
+                    (void)hipSetDevice(device);
+                    for (uint32_t i : live) {
+                        Slot &s = slots[i];
+                        if (fin[i]) continue;
+                        const int64_t n = fill_chunk(J, J.lane[1], i, s, s.d_chunk2);
+                        s.pre_n = n < 0 ? (n == -1 ? (int64_t)READ_ERROR : n) : n;
+                        if (n < 0) break;
+                    }
+                });
+            }
             rc = CSCMI_EncodeDeviceChunkBatch((int)hs.size(), hs.data(), ptrs.data(), sizes.data());
+            if (reader.joinable()) reader.join();
             if (st) st->seconds_encode += now_s() - t0;
             if (rc) break;
         }
@@ -659,13 +706,12 @@ int encode_tasks(std::vector<Task> &tasks, const EmitFn &emit, const CSAOptions 
         // ---- streams whose task has no bytes left: EOF, flush, hand the blocks to the writer
         ts = now_s();
         hs.clear();
-        for (uint32_t i : live) if (slots[i].fi >= tasks[slots[i].task].files.size()) hs.push_back(slots[i].h);
+        for (uint32_t i : live) if (fin[i]) hs.push_back(slots[i].h);
         rc = CSCMI_FlushBatch((int)hs.size(), hs.data());                   // csa_worker.cpp:49, every finished stream in one round trip
         if (rc) break;
         for (uint32_t i : live) {
             Slot &s = slots[i];
-            Task &t = tasks[s.task];
-            if (s.fi < t.files.size()) continue;
+            if (!fin[i]) continue;
             CSCEnc_Destroy(s.h);
             s.h = nullptr;
             s.sink->finish();                                               // csa_io.h:596-603
@@ -679,7 +725,7 @@ int encode_tasks(std::vector<Task> &tasks, const EmitFn &emit, const CSAOptions 
         rc = flush_written();
     }
     if (rc == 0) rc = flush_written();
-    if (st) st->raw_bytes += J.raw_bytes;
+    if (st) st->raw_bytes += J.lane[0].raw_bytes + J.lane[1].raw_bytes;
     for (BlockSink *k : done) delete k;
     free_job(J, slots);
     return rc;

@@ -68,7 +68,8 @@ typedef struct CSAStats {
     double seconds_encode;           /* Add: inside the batched encoder calls; Extract/Test: decode wall time */
     uint32_t peak_streams;           /* Add: most task streams in flight at once */
     uint32_t reserved;
-    double seconds_io;               /* Add: file reads + uploads + adler32 kernel (not overlapped with encoding) */
+    double seconds_io;               /* Add: file reads + uploads + adler32 kernel on the calling thread -- a stream's FIRST chunk; the later
+                                        chunks are read by a second thread during the encode calls (round 5) and do not count here */
     double seconds_setup;            /* Add: creating / flushing / destroying the task encoders */
 } CSAStats;
 

@@ -114,6 +114,33 @@ def test_add_is_independent_of_stream_concurrency(csa, tmp_path, monkeypatch):
     assert cases.digest((tmp_path / csa_cases.ARCNAME).read_bytes()) == GOLD["many_files"]["archive_sha256"]
 
 
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref/csarc_ref not in this snapshot")
+def test_add_with_multi_chunk_tasks_reads_ahead_and_equals_the_reference(csa, tmp_path, monkeypatch):
+    """tasks of several 2 MiB chunks: from the second chunk on a stream's bytes come from the read-ahead thread that runs during the
+    batch encode call (csa_archive.cpp: FillLane 1 -- the reference's reader thread, csa_io.h:215-272), the adler32 pieces of those
+    chunks are folded one round later.  The archive must still be the reference archiver's, byte for byte; an empty file, a file
+    that ends exactly at a chunk boundary and one that is a chunk plus one byte ride along."""
+    files = {"d/big1.bin": [["silesia", 31, 0, 9 << 20]], "d/big2.txt": [["text", 32, 0, (5 << 20) + 12345]], "d/edge.bin": [["exe", 33, 0, 2 << 20]],
+             "d/edge1.bin": [["exe", 34, 0, (2 << 20) + 1]], "d/edge2.bin": [["delta", 35, 0, 300000]], "d/small.txt": [["text", 36, 0, 70000]], "d/empty.txt": []}
+    for rel, parts in files.items():
+        path = tmp_path / rel
+        path.parent.mkdir(parents=True, exist_ok=True)
+        path.write_bytes(cases.build(parts))
+        os.chmod(path, 0o644)
+        os.utime(path, (csa_cases.MTIME, csa_cases.MTIME))
+    os.chmod(tmp_path / "d", 0o755)
+    os.utime(tmp_path / "d", (csa_cases.MTIME, csa_cases.MTIME))
+    monkeypatch.chdir(tmp_path)
+    rc, st = csa.add("mine.csa", ["d"], level=1, dict_size=4 << 20, recurse=True, overwrite=True)
+    assert rc == 0 and st["raw_bytes"] == sum(len(cases.build(p)) for p in files.values())
+    subprocess.run([CSARC_REF, "a", "-m1", "-d4m", "-r", "-t1", "-f", "ref0.csa", "d"], cwd=tmp_path, check=True, capture_output=True)
+    mine, ref = (tmp_path / "mine.csa").read_bytes(), (tmp_path / "ref0.csa").read_bytes()
+    # (the archive name's length enters the index: same length on both sides)
+    assert len("mine.csa") == len("ref0.csa") and mine == ref
+    rc, st2 = csa.test("mine.csa", [])
+    assert rc == 0 and st2["verify_failures"] == 0
+
+
 def test_add_refuses_to_overwrite(csa, tmp_path, monkeypatch):
     csa_cases.make_tree(str(tmp_path), "no_data")
     monkeypatch.chdir(tmp_path)
