@@ -748,6 +748,7 @@ DEV void bt_parser_call(Sc &, uint32_t) {}
 DEV void bt_inserter_call(Sc &) {}
 DEV void bt_post_call(Sc &) {}
 DEV void bt_coder_call(Sc &) {}
+DEV void bt_finder_call(Sc &) {}
 DEV void bt_init(Sc &, uint32_t) {}
 DEV void bt_inserter(Sc &) {}
 DEV void bt_post(Sc &) {}
