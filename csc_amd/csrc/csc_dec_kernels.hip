@@ -451,16 +451,18 @@ DDEV void dlz_decode(Dc &c, uint32_t limit)
             wr_kind = 2; wr_from = from; wr_dist = dist; wr_len = len; ni = i + len;
         }
         if (wr_kind == 2) DTM_ADD(c, 1);
-        if (UNLIKELY(c.undo_n > kDecUndoCap)) c.err = 1;
-        if (UNLIKELY(c.err)) { c.status = DEC_ERR_DECODE; return; }
-        if (UNLIKELY(c.need)) {          // ran out of input inside this packet: take it back, resume here later
-            if (!c.careful) { c.status = DEC_ERR_DECODE; return; }   // unreachable: see `careful` above
-            ck_rollback(c, k);
-            c.i = i; c.copied = copied; c.copied_from = copied_from;
-            return;
+        // the four rare outcomes of a packet behind ONE test (a not-taken scalar branch each, four a packet, adds up on this chain)
+        if (UNLIKELY(((c.undo_n > kDecUndoCap ? 1u : 0u) | c.err | c.need | (end ? 1u : 0u)) != 0)) {
+            if (c.undo_n > kDecUndoCap) c.err = 1;
+            if (c.err) { c.status = DEC_ERR_DECODE; return; }
+            if (c.need) {          // ran out of input inside this packet: take it back, resume here later
+                if (!c.careful) { c.status = DEC_ERR_DECODE; return; }   // unreachable: see `careful` above
+                ck_rollback(c, k);
+                c.i = i; c.copied = copied; c.copied_from = copied_from;
+                return;
+            }
+            break;                 // the terminator
         }
-        if (UNLIKELY(c.err)) { c.status = DEC_ERR_DECODE; return; }
-        if (UNLIKELY(end)) break;
         if (wr_kind == 1) { if (c.lane == 0) c.wnd[c.wnd_pos] = (uint8_t)wr_byte; c.wnd_pos++; }
         else if (wr_kind == 2) {
             c.ctx = dcopy_match(c, wr_from, wr_dist, wr_len);
@@ -468,8 +470,8 @@ DDEV void dlz_decode(Dc &c, uint32_t limit)
         }
         i = ni;
         DTM_ADD(c, 2);
-        if (UNLIKELY(c.wnd_pos > c.wnd_size)) { c.status = DEC_ERR_DECODE; return; }
-        if (UNLIKELY(c.wnd_pos == c.wnd_size)) {
+        if (UNLIKELY(c.wnd_pos >= c.wnd_size)) {
+            if (c.wnd_pos > c.wnd_size) { c.status = DEC_ERR_DECODE; return; }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             for (uint32_t t = c.lane; t < i - copied; t += 64) c.out[copied + t] = c.wnd[copied_from + t];
             c.wnd_pos = 0;
