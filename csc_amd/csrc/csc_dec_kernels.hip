@@ -28,18 +28,34 @@ typedef __attribute__((address_space(1))) uint8_t dgu8;
 typedef __attribute__((address_space(1))) uint32_t dgu32;
 typedef __attribute__((address_space(1))) DecState gDecState;   // the stream state, known to live in global memory
 
-// LDS image of one stream (dynamic shared memory, 138 KiB: one stream per CU).  The order-1 literal table --
+// LDS image of one stream (138 KiB: one stream per CU).  The order-1 literal table --
 // 65 536 twelve-bit probabilities, the table every literal walks 8 levels of -- lives here as u16 for the whole
 // launch (HBM image: DecState::p_lit reinterpreted as u16[65536]); so do the small tables and the head of the
 // undo journal.  p_delta (DT_DLT runs only) stays in HBM.
 constexpr uint32_t kUjLds = 256;
+// hand-over block between the Decompress state machine and the fast packet loop (dlz_fast)
+struct DecHand {
+    uint32_t d_lo, d_hi;                 // the stream's DecState
+    uint32_t rd[2], fill[2], slot[2];    // read offsets / payload sizes / ring slots of the current BC and RC blocks
+    uint32_t range, code, bc_bits, bc_val, state, ctx, rep[4], wnd_pos, i, limit, ret;
+#ifdef CSCMI_TIMERS
+    unsigned long long tm[16];
+#endif
+};
 struct DecLds {
     uint32_t P[P_COUNT + 4];
+    DecHand hand;
     uint32_t wtab[128];   // the dictionary filter's words, 4 chars packed per entry (0-terminated)
-    uint2 uj[kUjLds];     // undo journal, first kUjLds entries of a packet: (table | index, old value)
+    uint2 uj[kUjLds + 1]; // undo journal, first kUjLds entries of a packet: (table | index, old value); the last entry is a dump
     uint16_t plit[65536];
+    uint16_t plit_dump[8];   // where the lanes that hold no node of a literal's path put their "update" (see tree_update)
 };
 constexpr uint32_t kDecLdsBytes = sizeof(DecLds);
+constexpr uint32_t kPDump = P_COUNT + 3;      // the same for the small tables (P[] has four words of slack)
+// A file-scope image, not dynamic shared memory: the functions outside the kernel body (dlz_fast, the filters) then address it
+// with constants -- the base of a dynamic allocation is looked up in memory (an s_load + wait inside the packet loop).
+__shared__ __attribute__((aligned(16))) DecLds g_dec_lds;
+#define DEC_LDS (&g_dec_lds)
 
 #ifdef CSCMI_TIMERS
 #define DTM_DECL unsigned long long dtm__ = __builtin_readcyclecounter()
@@ -56,6 +72,8 @@ struct Dc {
     gDecState *D;
     DecLds *L;
     dgu8 *wnd, *out, *q[2];
+    dgu8 *blk[2];       // fast loop only: the current BC / RC block
+    uint32_t fast;      // 1 inside dlz_fast (a constant of the function it is set in: the tests on it fold away)
     dgu32 *p_delta, *qsize[2], *undo_addr, *undo_val;
     uint32_t wnd_size, bsize, qslots, lane;
     uint32_t avail[2], taken[2], rd[2], fill[2];
@@ -70,7 +88,7 @@ struct Dc {
     uint32_t phase, type, run_size, i, copied, copied_from, status, out_size, p_delta_ready;
 };
 
-__device__ static const uint32_t kDltIndexD[5] = {1, 2, 3, 4, 8};   // csc_typedef.h:36
+// channel counts of the delta types: {1, 2, 3, 4, 8}, csc_typedef.h:36 (as arithmetic at the one place that needs it)
 
 // scalar snapshot taken at every packet / symbol / int boundary
 struct Ck {
@@ -113,17 +131,20 @@ DDEV void ck_rollback(Dc &c, const Ck &k)
 // DecodeBit / coder_decode_direct do (csc_dec.cpp:14-21, 70-76)
 DDEV uint32_t next_byte(Dc &c, int kind)
 {
-    if (UNLIKELY(c.need)) return 0;
+    if (!c.fast && UNLIKELY(c.need)) return 0;
     // bytes are served from a 64-byte register window over the current block (one HBM fetch per 64 bytes)
     if (UNLIKELY(c.woff[kind] >= 64)) {
-        uint32_t slot = (c.taken[kind] - 1) % c.qslots;
-        c.bv[kind] = c.q[kind][(size_t)slot * c.bsize + c.rd[kind] + c.lane];   // ring has 64 bytes of slack
+        if (c.fast) c.bv[kind] = c.blk[kind][c.rd[kind] + c.lane];
+        else {
+            uint32_t slot = (c.taken[kind] - 1) % c.qslots;
+            c.bv[kind] = c.q[kind][(size_t)slot * c.bsize + c.rd[kind] + c.lane];   // ring has 64 bytes of slack
+        }
         c.woff[kind] = 0;
     }
     uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)c.bv[kind], (int)c.woff[kind]);
     c.woff[kind]++;
     c.rd[kind]++;
-    if (UNLIKELY(c.rd[kind] >= c.fill[kind])) {
+    if (!c.fast && UNLIKELY(c.rd[kind] >= c.fill[kind])) {    // (the fast loop stays clear of a block's end)
         if (c.taken[kind] < c.avail[kind]) {
             c.consumed += c.rd[kind];
             uint32_t ns = c.taken[kind] % c.qslots;
@@ -198,22 +219,52 @@ DDEV uint32_t p_update(uint32_t p, uint32_t bit)
     const uint32_t d = (p ^ (bit ? 0xFFFu : 0u)) >> 5;
     return bit ? p + d : p - d;
 }
+// ---- lane-divergent work lives OUTSIDE the packet loop's control flow --------------------------------------------------
+// Rounds 1-5 kept the whole stream context in VECTOR registers (a 215-VGPR loop with thirty v_mov phi copies at its head,
+// an exec-mask branch for every scalar test): the compiler's uniformity analysis marks EVERY phi of a block in which the two
+// sides of a lane-dependent branch meet as divergent, and after block merging those blocks were the packet loop's own
+// latches -- one `if (lane == 0)` or `for (j = lane; ...)` made range, code, positions and counters per-lane data.  So:
+// inside the loops that carry the stream's scalars a lane-dependent choice is a SELECT (of an address: lanes with nothing
+// to store write to a dump slot), and lane-strided loops are functions of their own (`__noinline__`: their joins are not
+// the caller's).  tools/dec_uniformity.sh prints what the analysis says about the kernel.
+#define DNOINL __device__ __noinline__
+DNOINL void d_copy_bytes(dgu8 *dst, const dgu8 *src, uint32_t n)
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    for (uint32_t t = threadIdx.x & 63u; t < n; t += 64) dst[t] = src[t];
+}
+DNOINL void d_fill_bytes(dgu8 *dst, uint32_t n, uint32_t v)
+{
+    for (uint32_t t = threadIdx.x & 63u; t < n; t += 64) dst[t] = (uint8_t)v;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
+DNOINL void d_fill_words(dgu32 *dst, uint32_t n, uint32_t v)
+{
+    for (uint32_t t = threadIdx.x & 63u; t < n; t += 64) dst[t] = v;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
 // journal address: bits 31:30 = table (0 small tables in LDS, 1 p_lit in LDS, 2 p_delta in HBM)
+// entries behind the LDS part of the journal (a packet of more than kUjLds bits: long-length chains only)
+DNOINL void d_journal_far(dgu32 *ua, dgu32 *uv, bool on, uint32_t slot, uint32_t addr, uint32_t old)
+{
+    if (on && slot >= kUjLds && slot < kUjLds + kDecUndoCap) { ua[slot - kUjLds] = addr; uv[slot - kUjLds] = old; }
+}
+DNOINL void d_store_word(dgu32 *p, bool on, uint32_t v) { if (on) *p = v; }
+// one entry per lane that holds a node of the path (`on`), at journal slot `slot` (per lane)
+DDEV void journal_lanes(Dc &c, bool on, uint32_t slot, uint32_t addr, uint32_t old, uint32_t slot_max)
+{
+    c.L->uj[on && slot < kUjLds ? slot : kUjLds] = make_uint2(addr, old);
+    if (UNLIKELY(slot_max >= kUjLds)) d_journal_far(c.undo_addr, c.undo_val, on, slot, addr, old);
+}
+// one entry, the same in every lane
 DDEV void journal_put(Dc &c, uint32_t slot, uint32_t addr, uint32_t old)
 {
-    if (slot < kUjLds) c.L->uj[slot] = make_uint2(addr, old);
+    if (LIKELY(slot < kUjLds)) c.L->uj[slot] = make_uint2(addr, old);
     else if (slot < kUjLds + kDecUndoCap) { c.undo_addr[slot - kUjLds] = addr; c.undo_val[slot - kUjLds] = old; }
-}
-template <int SPACE>
-DDEV void p_store(Dc &c, uint32_t idx, uint32_t np)
-{
-    if (SPACE == 0) c.L->P[idx] = np;
-    else if (SPACE == 1) c.L->plit[idx] = (uint16_t)np;
-    else c.p_delta[idx] = np;
 }
 // After an NB-bit tree has been decoded to `v` (leading 1 included): lane-parallel update of the NB nodes on the
 // path.  Each lane holds in `g` the probability of tree node `node` (heap numbering, 1 = root; anything outside
-// [1, 2^NB) = not a node of this tree) stored at table index `idx`.
+// [1, 2^NB) = not a node of this tree) stored at table index `idx`.  Lanes off the path store to a dump slot.
 template <int NB, int SPACE>
 DDEV void tree_update(Dc &c, uint32_t g, uint32_t v, uint32_t node, uint32_t idx)
 {
@@ -221,10 +272,11 @@ DDEV void tree_update(Dc &c, uint32_t g, uint32_t v, uint32_t node, uint32_t idx
     const uint32_t sh = (uint32_t)NB - depth;                              // v >> sh is the path's node at that depth
     const bool on = node >= 1u && node < (1u << NB) && (v >> (sh & 31u)) == node;
     const uint32_t bit = (v >> ((sh - 1u) & 31u)) & 1u;
-    if (on) {
-        if (UNLIKELY(c.careful)) journal_put(c, c.undo_n + depth, idx | ((uint32_t)SPACE << 30), g);
-        p_store<SPACE>(c, idx, p_update(g, bit));
-    }
+    if (UNLIKELY(c.careful)) journal_lanes(c, on, c.undo_n + depth, idx | ((uint32_t)SPACE << 30), g, c.undo_n + NB);
+    const uint32_t np = p_update(g, bit);
+    if (SPACE == 0) c.L->P[on ? idx : kPDump] = np;
+    else if (SPACE == 1) ((uint16_t *)c.L->plit)[on ? idx : 65536u + (c.lane & 7u)] = (uint16_t)np;   // (plit_dump follows plit)
+    else d_store_word(c.p_delta + idx, on, np);
     c.undo_n += NB;
 }
 // one stand-alone bit under a small-table probability (packet flags, length-slot bits, the long-length escape)
@@ -259,8 +311,11 @@ DDEV uint32_t dget_int(Dc &c)                  // decode_int, csc_dec.cpp:90-97
 // 8 bits under an order-1 row.  The node of bit k depends on the bits before it, so instead of 8 dependent
 // fetches the 15 nodes of the top 4 levels are fetched at once (heap order: lane L = node L), then the 15
 // nodes of the 4-level subtree under the node reached.  `top` = the first fetch, issued by the caller.
+// The update of the lower subtree's path is left to the caller (dbyte_low_update): the literal loop first asks for what the
+// NEXT packet starts with and lets this update ride on those loads' latency.
+struct LowTree { uint32_t sub, h, sidx; };
 template <int SPACE>
-DDEV uint32_t dbyte_tree_from(Dc &c, uint32_t row, uint32_t top)
+DDEV uint32_t dbyte_bits(Dc &c, uint32_t row, uint32_t top, LowTree &lo)
 {
     const uint32_t L = c.lane & 15;
     uint32_t v = 1;
@@ -268,26 +323,37 @@ DDEV uint32_t dbyte_tree_from(Dc &c, uint32_t row, uint32_t top)
     for (int k = 0; k < 4; k++) v = rc_step(c, rl(top, v), v);
     // subtree under node v (16..31): lane L = 2^j + t  ->  node (v << j) + t
     const uint32_t j = 31u - (uint32_t)__builtin_clz(L | 1u);
-    const uint32_t sidx = row + (v << j) + (L - (1u << j));
-    const uint32_t sub = SPACE == 1 ? (uint32_t)c.L->plit[sidx] : (uint32_t)c.p_delta[sidx];
+    lo.sidx = row + (v << j) + (L - (1u << j));
+    lo.sub = SPACE == 1 ? (uint32_t)c.L->plit[lo.sidx] : (uint32_t)c.p_delta[lo.sidx];
     tree_update<4, SPACE>(c, top, v, c.lane < 16 ? L : 0u, row + L);
     uint32_t h = 1;
 #pragma unroll
-    for (int k = 0; k < 4; k++) h = rc_step(c, rl(sub, h), h);
-    tree_update<4, SPACE>(c, sub, h, c.lane < 16 ? L : 0u, sidx);
+    for (int k = 0; k < 4; k++) h = rc_step(c, rl(lo.sub, h), h);
+    lo.h = h;
     return ((v << 4) | (h & 15u)) & 0xFF;
+}
+template <int SPACE>
+DDEV void dbyte_low_update(Dc &c, const LowTree &lo) { tree_update<4, SPACE>(c, lo.sub, lo.h, c.lane < 16 ? (c.lane & 15) : 0u, lo.sidx); }
+template <int SPACE>
+DDEV uint32_t dbyte_tree_from(Dc &c, uint32_t row, uint32_t top)
+{
+    LowTree lo;
+    const uint32_t b = dbyte_bits<SPACE>(c, row, top, lo);
+    dbyte_low_update<SPACE>(c, lo);
+    return b;
 }
 DDEV uint32_t dbyte_tree_l(Dc &c, uint32_t row) { return dbyte_tree_from<1>(c, row, c.L->plit[row + (c.lane & 15)]); }
 DDEV uint32_t dbyte_tree_g(Dc &c, uint32_t row) { return dbyte_tree_from<2>(c, row, c.p_delta[row + (c.lane & 15)]); }   // p_delta row (HBM)
 
-// decode_matchlen_1 (csc_dec.cpp:187-220).  P_LEN_SLOT[2], P_LEN_X1[8], P_LEN_X2[8], P_LEN_X3[128] are
-// contiguous: three lane-parallel LDS reads fetch every node any length can touch.
+// decode_matchlen_1 (csc_dec.cpp:187-220).  P_LEN_SLOT[2], P_LEN_X1[8], P_LEN_X2[8], P_LEN_X3[128] are contiguous: one lane-parallel
+// LDS read holds the two slot flags, both 3-bit trees and the top three levels of the 7-bit tree; its lower four levels (rare:
+// lengths from 18) are a second gather under the node reached, as in a literal's tree.
 DDEV uint32_t dmatchlen_1(Dc &c)
 {
-    const uint32_t i0 = P_LEN_SLOT + c.lane, i1 = P_LEN_SLOT + 64 + c.lane, i2 = P_LEN_SLOT + 128 + (c.lane & 31);
-    const uint32_t g0 = c.L->P[i0], g1 = c.L->P[i1], g2 = c.L->P[i2];
+    const uint32_t i0 = P_LEN_SLOT + c.lane;
+    const uint32_t g0 = c.L->P[i0];
     rc_scalar(c);          // (this bit follows joins of the packet's control flow: see rc_scalar)
-    if (dbit_p(c, P_LEN_SLOT, rl(g0, 0)) == 0) {                              // 3-bit tree, lengths 0..7
+    if (LIKELY(dbit_p(c, P_LEN_SLOT, rl(g0, 0)) == 0)) {                      // 3-bit tree, lengths 0..7
         uint32_t i = 1;
 #pragma unroll
         for (int k = 0; k < 3; k++) i = rc_step(c, rl(g0, (P_LEN_X1 - P_LEN_SLOT) + i), i);
@@ -301,21 +367,21 @@ DDEV uint32_t dmatchlen_1(Dc &c)
         tree_update<3, 0>(c, g0, i, i0 - P_LEN_X2, i0);
         return 8u + (i & 7u);
     }
-    uint32_t i = 1;                                                           // 7-bit tree, lengths 16..143
+    static_assert(P_LEN_X3 - P_LEN_SLOT + 7 < 64, "the 7-bit tree's nodes 1-7 lie in the first gather");
+    uint32_t i = 1;                                                           // 7-bit tree, lengths 16..143: nodes 1-7 from g0
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-        const uint32_t o = (P_LEN_X3 - P_LEN_SLOT) + i;                       // 19 .. 145
-        const uint32_t p = o < 64 ? rl(g0, o) : (o < 128 ? rl(g1, o - 64) : rl(g2, o - 128));
-        i = rc_step(c, p, i);
-    }
-    // the 7 path nodes live in up to three registers; every lane checks its own node in each (undo_n advances once)
-    {
-        const uint32_t n0 = c.undo_n;
-        tree_update<7, 0>(c, g0, i, i0 - P_LEN_X3, i0); c.undo_n = n0;
-        tree_update<7, 0>(c, g1, i, i1 - P_LEN_X3, i1); c.undo_n = n0;
-        tree_update<7, 0>(c, g2, i, c.lane < 32 ? i2 - P_LEN_X3 : 0u, i2);
-    }
-    return 16u + (i & 127u);
+    for (int k = 0; k < 3; k++) i = rc_step(c, rl(g0, (P_LEN_X3 - P_LEN_SLOT) + i), i);
+    // the subtree under node i (8..15): lane L = 2^j + t (L = 1..15)  ->  node (i << j) + t
+    const uint32_t L = c.lane & 15;
+    const uint32_t j = 31u - (uint32_t)__builtin_clz(L | 1u);
+    const uint32_t sidx = P_LEN_X3 + (i << j) + (L - (1u << j));
+    const uint32_t sub = c.L->P[sidx];
+    tree_update<3, 0>(c, g0, i, i0 - P_LEN_X3, i0);
+    uint32_t h = 1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) h = rc_step(c, rl(sub, h), h);
+    tree_update<4, 0>(c, sub, h, c.lane < 16 ? L : 0u, sidx);
+    return 16u + (((i << 4) | (h & 15u)) & 127u);
 }
 DDEV uint32_t dmatchlen_2(Dc &c)               // csc_dec.cpp:222-234
 {
@@ -367,113 +433,242 @@ DDEV void dmatch(Dc &c, uint32_t &dist, uint32_t &len)   // decode_match, csc_de
 }
 
 // window copy of a match: dst[j] = src[j] in increasing j, i.e. a pattern repeat when the regions
-// overlap (csc_dec.cpp:513-518) -- lane-parallel with the modulo made explicit.  The wait for earlier window
-// stores sits in front of the loads (by now those stores have had a whole packet's decoding time to land);
-// nothing waits behind the stores.  Returns the last byte copied (the next literal context).
-DDEV uint32_t dcopy_match(Dc &c, uint32_t from, uint32_t dist, uint32_t len)
+// overlap (csc_dec.cpp:513-518) -- lane-parallel with the modulo made explicit.  Earlier window stores of THIS wavefront
+// are ordered before these loads by the hardware (one wavefront's vector memory operations execute in order through one
+// L1); nothing waits behind the stores.  Returns the last byte copied (the next literal context) -- in every lane, but as
+// the result of a call: the caller passes it through v_readfirstlane.  A function of its own: see DNOINL above.
+DNOINL uint32_t d_copy_match(dgu8 *w, uint32_t from, uint32_t to, uint32_t dist, uint32_t len)
 {
-    dgu8 *w = c.wnd;
-    const uint32_t to = c.wnd_pos;
+    const uint32_t lane = threadIdx.x & 63u;
     const bool overlap = from < to && from + len > to;   // then dist = to - from < len
-    // earlier window stores of THIS wavefront are ordered before these loads by the hardware (one wavefront's vector
-    // memory operations execute in order through one L1); the fence only pins the compiler's order
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     uint32_t last = 0;
     if (!overlap) {
-        for (uint32_t j = c.lane; j < len; j += 64) { last = w[from + j]; w[to + j] = (uint8_t)last; }
+        for (uint32_t j = lane; j < len; j += 64) { last = w[from + j]; w[to + j] = (uint8_t)last; }
     } else {
         // every source byte is one of the `dist` bytes in front of `to`: fetch those once, then replicate
-        for (uint32_t j = c.lane; j < len; j += 64) { last = w[from + j % dist]; w[to + j] = (uint8_t)last; }
+        for (uint32_t j = lane; j < len; j += 64) { last = w[from + j % dist]; w[to + j] = (uint8_t)last; }
     }
     return rl(last, (len - 1) & 63u);
 }
+DDEV uint32_t dcopy_match(Dc &c, uint32_t from, uint32_t dist, uint32_t len) { return DUNI(d_copy_match(c.wnd, from, c.wnd_pos, dist, len)); }
 
-// CSCDecoder::lz_decode body, csc_dec.cpp:476-571, one packet per loop turn, checkpointed per packet
+// One packet of CSCDecoder::lz_decode (csc_dec.cpp:476-571): the bits, the model updates, the new rep distances / state; the
+// window write it asks for comes back in `w` (the caller does it once the packet is known to stand).
+struct Wr { uint32_t kind, from, dist, len, byte; };     // kind 0 nothing (the terminator), 1 a literal, 2 a copy
+// what a packet can start with -- the three packet-kind flags, the two rep-index flags that can follow (lanes 0-2 / 3-5) and the
+// top of the literal tree under the current context -- in one LDS round trip; then the first flag.  True: a literal follows.
+DDEV bool dlz_packet_head(Dc &c, uint32_t &st3, uint32_t &fl, uint32_t &lrow, uint32_t &ltop)
+{
+    st3 = c.state * 3;
+    fl = c.L->P[(c.lane < 3 ? P_STATE : P_REPDIST - 3) + st3 + (c.lane < 6 ? c.lane : 5)];
+    lrow = c.ctx * 256;
+    ltop = c.L->plit[lrow + (c.lane & 15)];
+    return dbit_p(c, P_STATE + st3, rl(fl, 0)) == 0;
+}
+DDEV uint32_t dlz_literal(Dc &c, uint32_t lrow, uint32_t ltop)
+{
+    const uint32_t b = dbyte_tree_from<1>(c, lrow, ltop);
+    c.ctx = b;
+    c.state = (c.state * 4) & 0x3F;
+    return b;
+}
+// the packet kinds behind a set first flag
+DDEV void dlz_packet_rest(Dc &c, uint32_t st3, uint32_t fl, uint32_t i, uint32_t limit, uint32_t &ni, bool &end, Wr &w)
+{
+    ni = i; end = false;
+    w.kind = 0; w.from = 0; w.dist = 0; w.len = 0; w.byte = 0;
+    if (dbit_p(c, P_STATE + st3 + 1, rl(fl, 1)) == 1) {
+        uint32_t dist, len;
+        dmatch(c, dist, len);
+        if (len == 0 && dist == 64) end = true;
+        else {
+            dist++; len += 2;
+            c.rep[3] = c.rep[2]; c.rep[2] = c.rep[1]; c.rep[1] = c.rep[0]; c.rep[0] = dist;
+            uint32_t from = c.wnd_pos >= dist ? c.wnd_pos - dist : c.wnd_pos + c.wnd_size - dist;
+            if (from >= c.wnd_size || from + len > c.wnd_size || len + i > limit || c.wnd_pos + len > c.wnd_size) c.err = 1;
+            w.kind = 2; w.from = from; w.dist = dist; w.len = len; ni = i + len;
+        }
+    } else if (dbit_p(c, P_STATE + st3 + 2, rl(fl, 2)) == 0) {
+        c.state = (c.state * 4 + 2) & 0x3F;
+        uint32_t from = c.wnd_pos > c.rep[0] ? c.wnd_pos - c.rep[0] : c.wnd_pos + c.wnd_size - c.rep[0];
+        if (from > c.wnd_size) c.err = 1;   // the reference reads out of bounds here on corrupt input
+        w.kind = 2; w.from = from; w.dist = c.rep[0]; w.len = 1; ni = i + 1;
+    } else {
+        uint32_t kk = 2u + dbit_p(c, P_REPDIST + st3, rl(fl, 3));
+        kk = kk + kk + dbit_p(c, P_REPDIST + st3 + kk - 1, rl(fl, 3 + kk - 1));
+        uint32_t idx = kk & 3, len = dmatchlen_2(c) + 2;
+        c.state = (c.state * 4 + 3) & 0x3F;
+        if (len + i > limit) c.err = 1;
+        // move-to-front as selects: a dynamic index would push the whole stream context into scratch memory
+        const uint32_t r0 = c.rep[0], r1 = c.rep[1], r2 = c.rep[2], r3 = c.rep[3];
+        uint32_t dist = idx == 0 ? r0 : idx == 1 ? r1 : idx == 2 ? r2 : r3;
+        c.rep[3] = idx >= 3 ? r2 : r3;
+        c.rep[2] = idx >= 2 ? r1 : r2;
+        c.rep[1] = idx >= 1 ? r0 : r1;
+        c.rep[0] = dist;
+        uint32_t from = c.wnd_pos >= dist ? c.wnd_pos - dist : c.wnd_pos + c.wnd_size - dist;
+        if (from >= c.wnd_size || from + len > c.wnd_size || len + i > limit || c.wnd_pos + len > c.wnd_size) c.err = 1;
+        w.kind = 2; w.from = from; w.dist = dist; w.len = len; ni = i + len;
+    }
+}
+DDEV void dlz_packet(Dc &c, uint32_t i, uint32_t limit, uint32_t &ni, bool &end, Wr &w)
+{
+    uint32_t st3, fl, lrow, ltop;
+    if (dlz_packet_head(c, st3, fl, lrow, ltop)) {
+        end = false; ni = i + 1;
+        w.kind = 1; w.from = 0; w.dist = 0; w.len = 0; w.byte = dlz_literal(c, lrow, ltop);
+    } else dlz_packet_rest(c, st3, fl, i, limit, ni, end, w);
+}
+// the window write of a packet that stands
+DDEV void dlz_write(Dc &c, const Wr &w)
+{
+    if (w.kind == 1) { c.wnd[c.wnd_pos] = (uint8_t)w.byte; c.wnd_pos++; }   // (every lane the same byte to the same place)
+    else if (w.kind == 2) {
+        c.ctx = dcopy_match(c, w.from, w.dist, w.len);
+        c.wnd_pos += w.len;
+    }
+}
+// A packet is journalled (and the scalars checkpointed) only if the input could run out inside it: fewer than
+// kDecUndoCap/8 + 64 coded bytes left in the current RC block, or fewer than 16 in the BC block.  Everywhere
+// else -- 93 % of a 64 KiB block -- a packet cannot exhaust its block before the kDecUndoCap-bit limit stops it.
+DDEV bool dlz_careful_zone(const Dc &c) { return c.rd[1] + kDecUndoCap / 8 + 64 > c.fill[1] || c.rd[0] + 16 > c.fill[0]; }
+
+// The packets outside the careful zones -- nothing to journal, no block can end -- run in a loop, and a FUNCTION, of their
+// own: what it carries from packet to packet is a dozen scalars, not the Decompress state machine's context with its
+// checkpoint, and its registers are its own (no argument: it finds the stream through the hand-over block in LDS and
+// puts it back there).  hand.ret: 0 = went as far as it may (a careful zone, the end of the run, the end of the window:
+// the caller looks), 1 = the terminator packet was decoded, 2 = a packet that cannot be (DECODE_ERROR).
+DNOINL void dlz_fast()
+{
+    DecLds *const L = DEC_LDS;
+    DecHand &H = L->hand;
+    Dc c;
+    gDecState *const D = (gDecState *)(((uint64_t)DUNI(H.d_hi) << 32) | DUNI(H.d_lo));
+    auto U64 = [](uint64_t v) { return ((uint64_t)DUNI((uint32_t)(v >> 32)) << 32) | DUNI((uint32_t)v); };
+    c.D = D; c.L = L; c.lane = threadIdx.x & 63u;
+    c.wnd = (dgu8 *)U64((uint64_t)D->wnd);
+    c.wnd_size = DUNI(D->wnd_size);
+    const uint32_t bsize = DUNI(D->bsize);
+    c.blk[0] = (dgu8 *)U64((uint64_t)D->q[0]) + (size_t)DUNI(H.slot[0]) * bsize;
+    c.blk[1] = (dgu8 *)U64((uint64_t)D->q[1]) + (size_t)DUNI(H.slot[1]) * bsize;
+    c.fast = 1; c.careful = 0; c.need = 0; c.err = 0; c.undo_n = 0;
+    c.rd[0] = DUNI(H.rd[0]); c.rd[1] = DUNI(H.rd[1]); c.fill[0] = DUNI(H.fill[0]); c.fill[1] = DUNI(H.fill[1]);
+    c.range = DUNI(H.range); c.code = DUNI(H.code); c.bc_bits = DUNI(H.bc_bits); c.bc_val = DUNI(H.bc_val);
+    c.state = DUNI(H.state); c.ctx = DUNI(H.ctx); c.wnd_pos = DUNI(H.wnd_pos);
+    for (int r = 0; r < 4; r++) c.rep[r] = DUNI(H.rep[r]);
+    c.bv[0] = c.bv[1] = 0; c.woff[0] = c.woff[1] = 64;
+    uint32_t i = DUNI(H.i), ret = 0;
+    const uint32_t limit = DUNI(H.limit);
+#ifdef CSCMI_TIMERS
+    for (int t = 0; t < 16; t++) c.tm[t] = 0;
+#endif
+    for (;;) {
+        // the same tests as the caller's
+        if (UNLIKELY(i > limit || c.wnd_pos >= c.wnd_size || c.rd[1] + kDecUndoCap / 8 + 64 > c.fill[1] || c.rd[0] + 16 > c.fill[0])) break;
+        DTM_DECL;
+        uint32_t st3, fl, lrow, ltop;
+        // A run of literals is a loop of its own: nothing of a literal can fail, it moves only the coder's words, the context, the
+        // state and the two positions -- the rep distances and the bit coder's words are not carried round this loop.
+        if (LIKELY(dlz_packet_head(c, st3, fl, lrow, ltop))) {
+          bool stop;
+          do {
+            LowTree lo;
+            const uint32_t b = dbyte_bits<1>(c, lrow, ltop, lo);
+            c.ctx = b;
+            c.state = (c.state * 4) & 0x3F;
+            DTM_ADD(c, 0);
+            // what the next packet starts with is asked for NOW -- it hangs on the byte and the state only; the rest of this
+            // literal (its lower subtree's update: nodes 16-255, the next packet's gather reads nodes 1-15; the window store, the
+            // loop's tests) rides on the latency of these loads
+            // (volatile: the compiler would sink the flags' load behind the loop's tests, to where they are used)
+            st3 = c.state * 3;
+            fl = *(volatile __attribute__((address_space(3))) uint32_t *)&c.L->P[(c.lane < 3 ? P_STATE : P_REPDIST - 3) + st3 + (c.lane < 6 ? c.lane : 5)];
+            lrow = b * 256;
+            ltop = *(volatile __attribute__((address_space(3))) uint16_t *)&c.L->plit[lrow + (c.lane & 15)];
+            dbyte_low_update<1>(c, lo);
+            c.wnd[c.wnd_pos] = (uint8_t)b;          // (every lane the same byte to the same place)
+            c.wnd_pos++;
+            i++;
+            DTM_ADD(c, 2);
+            stop = i > limit || c.wnd_pos >= c.wnd_size || c.rd[1] + kDecUndoCap / 8 + 64 > c.fill[1];
+          } while (LIKELY(!stop) && LIKELY(dbit_p(c, P_STATE + st3, rl(fl, 0)) == 0));
+          if (UNLIKELY(stop)) break;     // (nothing of the next packet has been decoded)
+        }
+        c.undo_n = 1;
+        uint32_t ni; bool end; Wr w;
+        dlz_packet_rest(c, st3, fl, i, limit, ni, end, w);
+        DTM_ADD(c, 1);
+        if (UNLIKELY(((c.undo_n > kDecUndoCap ? 1u : 0u) | c.err | (end ? 1u : 0u)) != 0)) { ret = (c.err || c.undo_n > kDecUndoCap) ? 2u : 1u; break; }
+        dlz_write(c, w);
+        i = ni;
+        DTM_ADD(c, 2);
+    }
+    H.rd[0] = c.rd[0]; H.rd[1] = c.rd[1];
+    H.range = c.range; H.code = c.code; H.bc_bits = c.bc_bits; H.bc_val = c.bc_val;
+    H.state = c.state; H.ctx = c.ctx; H.wnd_pos = c.wnd_pos;
+    for (int r = 0; r < 4; r++) H.rep[r] = c.rep[r];
+    H.i = i; H.ret = ret;
+#ifdef CSCMI_TIMERS
+    for (int t = 0; t < 3; t++) { H.tm[t] += c.tm[t]; H.tm[8 + t] += c.tm[8 + t]; }
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
+
+// CSCDecoder::lz_decode, csc_dec.cpp:476-571: one packet per loop turn; checkpointed per packet inside the careful zones,
+// handed to dlz_fast outside them
 DDEV void dlz_decode(Dc &c, uint32_t limit)
 {
     uint32_t i = c.i, copied = c.copied, copied_from = c.copied_from;
     Ck k;
     for (; i <= limit;) {
-        DTM_DECL;
-        // A packet is journalled (and the scalars checkpointed) only if the input could run out inside it: fewer than
-        // kDecUndoCap/8 + 64 coded bytes left in the current RC block, or fewer than 16 in the BC block.  Everywhere
-        // else -- 93 % of a 64 KiB block -- a packet cannot exhaust its block before the kDecUndoCap-bit limit stops it.
-        c.careful = (c.rd[1] + kDecUndoCap / 8 + 64 > c.fill[1] || c.rd[0] + 16 > c.fill[0]) ? 1u : 0u;
-        c.undo_n = 0;
-        rc_scalar(c);
-        if (UNLIKELY(c.careful)) ck_take(c, k);
-        uint32_t ni = i;
+        const bool zone = dlz_careful_zone(c);
         bool end = false;
-        uint32_t wr_kind = 0, wr_from = 0, wr_dist = 0, wr_len = 0, wr_byte = 0;   // deferred window write of this packet
-        // the three packet-kind flags, the two rep-index flags that can follow (lanes 0-2 / 3-5) and the top of the
-        // literal tree under the current context: one LDS round trip for everything a packet can start with
-        const uint32_t st3 = c.state * 3;
-        const uint32_t fl = c.L->P[(c.lane < 3 ? P_STATE : P_REPDIST - 3) + st3 + (c.lane < 6 ? c.lane : 5)];
-        const uint32_t lrow = c.ctx * 256;
-        const uint32_t ltop = c.L->plit[lrow + (c.lane & 15)];
-        if (dbit_p(c, P_STATE + st3, rl(fl, 0)) == 0) {
-            uint32_t b = dbyte_tree_from<1>(c, lrow, ltop);
-            c.ctx = b;
-            c.state = (c.state * 4) & 0x3F;
-            wr_kind = 1; wr_byte = b; ni = i + 1;
-            DTM_ADD(c, 0);
-        } else if (dbit_p(c, P_STATE + st3 + 1, rl(fl, 1)) == 1) {
-            uint32_t dist, len;
-            dmatch(c, dist, len);
-            if (len == 0 && dist == 64) end = true;
-            else {
-                dist++; len += 2;
-                c.rep[3] = c.rep[2]; c.rep[2] = c.rep[1]; c.rep[1] = c.rep[0]; c.rep[0] = dist;
-                uint32_t from = c.wnd_pos >= dist ? c.wnd_pos - dist : c.wnd_pos + c.wnd_size - dist;
-                if (from >= c.wnd_size || from + len > c.wnd_size || len + i > limit || c.wnd_pos + len > c.wnd_size) c.err = 1;
-                wr_kind = 2; wr_from = from; wr_dist = dist; wr_len = len; ni = i + len;
-            }
-        } else if (dbit_p(c, P_STATE + st3 + 2, rl(fl, 2)) == 0) {
-            c.state = (c.state * 4 + 2) & 0x3F;
-            uint32_t from = c.wnd_pos > c.rep[0] ? c.wnd_pos - c.rep[0] : c.wnd_pos + c.wnd_size - c.rep[0];
-            if (from > c.wnd_size) c.err = 1;   // the reference reads out of bounds here on corrupt input
-            wr_kind = 2; wr_from = from; wr_dist = c.rep[0]; wr_len = 1; ni = i + 1;
+        if (LIKELY(!zone)) {
+            DecHand &H = c.L->hand;
+            H.rd[0] = c.rd[0]; H.rd[1] = c.rd[1]; H.fill[0] = c.fill[0]; H.fill[1] = c.fill[1];
+            H.slot[0] = (c.taken[0] - 1) % c.qslots; H.slot[1] = (c.taken[1] - 1) % c.qslots;
+            H.range = c.range; H.code = c.code; H.bc_bits = c.bc_bits; H.bc_val = c.bc_val;
+            H.state = c.state; H.ctx = c.ctx; H.wnd_pos = c.wnd_pos;
+            for (int r = 0; r < 4; r++) H.rep[r] = c.rep[r];
+            H.i = i; H.limit = limit;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            dlz_fast();
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            c.rd[0] = DUNI(H.rd[0]); c.rd[1] = DUNI(H.rd[1]);
+            c.range = DUNI(H.range); c.code = DUNI(H.code); c.bc_bits = DUNI(H.bc_bits); c.bc_val = DUNI(H.bc_val);
+            c.state = DUNI(H.state); c.ctx = DUNI(H.ctx); c.wnd_pos = DUNI(H.wnd_pos);
+            for (int r = 0; r < 4; r++) c.rep[r] = DUNI(H.rep[r]);
+            c.woff[0] = c.woff[1] = 64;
+            i = DUNI(H.i);
+            const uint32_t ret = DUNI(H.ret);
+            if (UNLIKELY(ret == 2)) { c.status = DEC_ERR_DECODE; return; }
+            end = ret == 1;
         } else {
-            uint32_t kk = 2u + dbit_p(c, P_REPDIST + st3, rl(fl, 3));
-            kk = kk + kk + dbit_p(c, P_REPDIST + st3 + kk - 1, rl(fl, 3 + kk - 1));
-            uint32_t idx = kk & 3, len = dmatchlen_2(c) + 2;
-            c.state = (c.state * 4 + 3) & 0x3F;
-            if (len + i > limit) c.err = 1;
-            // move-to-front as selects: a dynamic index would push the whole stream context into scratch memory
-            const uint32_t r0 = c.rep[0], r1 = c.rep[1], r2 = c.rep[2], r3 = c.rep[3];
-            uint32_t dist = idx == 0 ? r0 : idx == 1 ? r1 : idx == 2 ? r2 : r3;
-            c.rep[3] = idx >= 3 ? r2 : r3;
-            c.rep[2] = idx >= 2 ? r1 : r2;
-            c.rep[1] = idx >= 1 ? r0 : r1;
-            c.rep[0] = dist;
-            uint32_t from = c.wnd_pos >= dist ? c.wnd_pos - dist : c.wnd_pos + c.wnd_size - dist;
-            if (from >= c.wnd_size || from + len > c.wnd_size || len + i > limit || c.wnd_pos + len > c.wnd_size) c.err = 1;
-            wr_kind = 2; wr_from = from; wr_dist = dist; wr_len = len; ni = i + len;
-        }
-        if (wr_kind == 2) DTM_ADD(c, 1);
-        // the four rare outcomes of a packet behind ONE test (a not-taken scalar branch each, four a packet, adds up on this chain)
-        if (UNLIKELY(((c.undo_n > kDecUndoCap ? 1u : 0u) | c.err | c.need | (end ? 1u : 0u)) != 0)) {
-            if (c.undo_n > kDecUndoCap) c.err = 1;
-            if (c.err) { c.status = DEC_ERR_DECODE; return; }
-            if (c.need) {          // ran out of input inside this packet: take it back, resume here later
-                if (!c.careful) { c.status = DEC_ERR_DECODE; return; }   // unreachable: see `careful` above
+            DTM_DECL;
+            c.careful = 1;
+            c.undo_n = 0;
+            rc_scalar(c);
+            ck_take(c, k);
+            uint32_t ni; Wr w;
+            dlz_packet(c, i, limit, ni, end, w);
+            if (w.kind == 2) DTM_ADD(c, 1); else DTM_ADD(c, 0);
+            // the rare outcomes of a packet behind ONE test
+            if (UNLIKELY(((c.undo_n > kDecUndoCap ? 1u : 0u) | c.err | c.need) != 0)) {
+                if (c.undo_n > kDecUndoCap) c.err = 1;
+                if (c.err) { c.status = DEC_ERR_DECODE; return; }
+                // ran out of input inside this packet: take it back, resume here later
                 ck_rollback(c, k);
                 c.i = i; c.copied = copied; c.copied_from = copied_from;
                 return;
             }
-            break;                 // the terminator
+            if (!end) { dlz_write(c, w); i = ni; }
+            DTM_ADD(c, 2);
         }
-        if (wr_kind == 1) { if (c.lane == 0) c.wnd[c.wnd_pos] = (uint8_t)wr_byte; c.wnd_pos++; }
-        else if (wr_kind == 2) {
-            c.ctx = dcopy_match(c, wr_from, wr_dist, wr_len);
-            c.wnd_pos += wr_len;
-        }
-        i = ni;
-        DTM_ADD(c, 2);
+        if (UNLIKELY(end)) break;                 // the terminator
         if (UNLIKELY(c.wnd_pos >= c.wnd_size)) {
             if (c.wnd_pos > c.wnd_size) { c.status = DEC_ERR_DECODE; return; }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            for (uint32_t t = c.lane; t < i - copied; t += 64) c.out[copied + t] = c.wnd[copied_from + t];
+            d_copy_bytes(c.out + copied, c.wnd + copied_from, i - copied);
             c.wnd_pos = 0;
             copied_from = 0;
             copied = i;
@@ -481,8 +676,7 @@ DDEV void dlz_decode(Dc &c, uint32_t limit)
     }
     {
         DTM_DECL;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        for (uint32_t t = c.lane; t < i - copied; t += 64) c.out[copied + t] = c.wnd[copied_from + t];
+        d_copy_bytes(c.out + copied, c.wnd + copied_from, i - copied);
         DTM_ADD(c, 3);
     }
     c.out_size = i;
@@ -496,7 +690,7 @@ DDEV void dcopy2dict(Dc &c, uint32_t size)   // lz_copy2dict, csc_dec.cpp:573-58
     for (uint32_t i = 0; i < size;) {
         uint32_t cur = c.wnd_size - c.wnd_pos < size - i ? c.wnd_size - c.wnd_pos : size - i;
         if (cur > kMinBlock) cur = kMinBlock;
-        for (uint32_t t = c.lane; t < cur; t += 64) c.wnd[c.wnd_pos + t] = c.out[i + t];
+        d_copy_bytes(c.wnd + c.wnd_pos, c.out + i, cur);
         c.wnd_pos += cur;
         if (c.wnd_pos >= c.wnd_size) c.wnd_pos = 0;
         i += cur;
@@ -507,12 +701,12 @@ DDEV void dcopy2dict(Dc &c, uint32_t size)   // lz_copy2dict, csc_dec.cpp:573-58
 // ---- inverse filters on the decoded run in `out` ----
 // Inverse_E89 (csc_filters.cpp:560-575,600-610), unrolled like the forward filter: opcode candidates by
 // ballot, the skip chain over the sparse hits is serial, operands are rewritten in place.
-DDEV void dinverse_e89(Dc &c, uint32_t size)
+DNOINL void dinverse_e89(dgu8 *b, uint32_t size)
 {
-    dgu8 *b = c.out;
+    const uint32_t lane = threadIdx.x & 63u;
     uint32_t next_ok = 0;
     for (uint32_t base = 0; base + 5 < size; base += 64) {
-        uint32_t j0 = base + c.lane;
+        uint32_t j0 = base + lane;
         bool cand = false;
         if (j0 + 5 < size) cand = (b[j0] & 0xFEu) == 0xE8u;
         uint64_t m = __ballot(cand);
@@ -536,17 +730,17 @@ DDEV void dinverse_e89(Dc &c, uint32_t size)
 }
 
 // Inverse_Delta (csc_filters.cpp:371-399): a running byte sum over the de-interleaved order
-DDEV void dinverse_delta(Dc &c, uint32_t size, uint32_t chn)
+DNOINL void dinverse_delta(dgu8 *src, dgu8 *copy, uint32_t size, uint32_t chn)
 {
+    const uint32_t lane = threadIdx.x & 63u;
     if (size < 512) return;
-    dgu8 *src = c.out, *copy = (dgu8 *)c.D->swap;
-    for (uint32_t t = c.lane; t < size; t += 64) copy[t] = src[t];
+    for (uint32_t t = lane; t < size; t += 64) copy[t] = src[t];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     uint32_t carry = 0;
     for (uint32_t base = 0; base < size; base += 64) {
-        uint32_t n = base + c.lane;
+        uint32_t n = base + lane;
         uint32_t v = n < size ? copy[n] : 0;
-        for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(v, o); if ((int)c.lane >= o) v += t; }   // inclusive scan
+        for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(v, o); if ((int)lane >= o) v += t; }   // inclusive scan
         v = (v + carry) & 0xFF;
         if (n < size) {
             // n-th element of the de-interleaved order is position j = ch + idx * chn
@@ -569,31 +763,32 @@ DDEV void dinverse_delta(Dc &c, uint32_t size, uint32_t chn)
 // run markers and escaped bytes alternate); every lane then knows how many bytes it emits (0 marker, 1, or a
 // 2-4 letter word), an exclusive wave scan gives its output offset, and it stores its bytes.  The last 66 source
 // positions -- where the reference's `i + 1 < size` guard matters -- are walked serially like the reference does.
-DDEV void dinverse_dict(Dc &c, uint32_t size)
+DNOINL void dinverse_dict(dgu8 *src, dgu8 *dst, uint32_t size)
 {
-    dgu8 *src = c.out, *dst = (dgu8 *)c.D->swap;
+    const uint32_t lane = threadIdx.x & 63u;
+    DecLds *const lds = DEC_LDS;
     uint32_t i = 0, o = 0;
     uint32_t carry = 0;                                  // parity of the run of 254s that ends just before position i
     while (o < size && i + 66 < size) {
-        const uint32_t b = src[i + c.lane];              // `out` has slack behind `size`
+        const uint32_t b = src[i + lane];              // `out` has slack behind `size`
         const uint32_t nb_lane63 = DUNI((uint32_t)src[i + 64]);
         const uint64_t m254 = __ballot(b == 254);
         // r = number of consecutive 254s immediately below this lane (run reaching the chunk start continues the carry)
-        const uint64_t below = c.lane ? (m254 << (64 - c.lane)) : 0ull;            // bits [0, lane) moved to the top
-        uint32_t r = c.lane ? (uint32_t)__builtin_clzll(~below | ((1ull << (64 - c.lane)) - 1ull)) : 0u;
-        if (r > c.lane) r = c.lane;
-        const uint32_t par = (r + (r == c.lane ? carry : 0u)) & 1u;
+        const uint64_t below = lane ? (m254 << (64 - lane)) : 0ull;            // bits [0, lane) moved to the top
+        uint32_t r = lane ? (uint32_t)__builtin_clzll(~below | ((1ull << (64 - lane)) - 1ull)) : 0u;
+        if (r > lane) r = lane;
+        const uint32_t par = (r + (r == lane ? carry : 0u)) & 1u;
         const bool ge82 = b >= 0x82;
         const bool esc = par && ge82;                                                 // swallowed by the marker before it
         uint32_t nb = (uint32_t)__shfl_down((int)b, 1);
-        if (c.lane == 63) nb = nb_lane63;
+        if (lane == 63) nb = nb_lane63;
         const bool marker = b == 254 && !esc && nb >= 0x82;
         const bool word = !esc && b >= 0x82 && b < 0x82 + 122;
-        const uint32_t w = word ? c.L->wtab[b - 0x82] : b;
+        const uint32_t w = word ? lds->wtab[b - 0x82] : b;
         const uint32_t wl = word ? ((w >> 16) & 0xFF ? ((w >> 24) ? 4u : 3u) : 2u) : 1u;   // words have 2..4 letters
         const uint32_t n = marker ? 0u : wl;
         uint32_t x = n;                                                               // inclusive scan over the wave
-        for (int off = 1; off < 64; off <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)x, off); if ((int)c.lane >= off) x += t; }
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)x, off); if ((int)lane >= off) x += t; }
         const uint32_t at = o + x - n;
         for (uint32_t t = 0; t < n; t++) if (at + t < size) dst[at + t] = (uint8_t)(w >> (8 * t));
         // carry for the next chunk: parity of the run of 254s at the top of this one
@@ -612,14 +807,14 @@ DDEV void dinverse_dict(Dc &c, uint32_t size)
         }
         while (o < size) {
             const uint32_t base = i;
-            uint32_t v = src[base + c.lane];
+            uint32_t v = src[base + lane];
             uint32_t vn = DUNI((uint32_t)src[base + 64]);
             uint32_t j = 0;
             while (j < 64 && o < size) {
                 uint32_t b = rl(v, j);
                 if (escaped) { dst[o++] = (uint8_t)b; escaped = false; }
                 else if (b >= 0x82 && b < 0x82 + 122) {
-                    uint32_t w = DUNI(c.L->wtab[b - 0x82]);
+                    uint32_t w = DUNI(lds->wtab[b - 0x82]);
                     for (uint32_t t = 0; t < 4 && o < size; t++) {
                         uint32_t ch = (w >> (8 * t)) & 0xFF;
                         if (!ch) break;
@@ -636,7 +831,7 @@ DDEV void dinverse_dict(Dc &c, uint32_t size)
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    for (uint32_t t = c.lane; t < size; t += 64) src[t] = dst[t];
+    for (uint32_t t = lane; t < size; t += 64) src[t] = dst[t];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 }
 
@@ -681,10 +876,14 @@ DDEV void decode_stream(gDecState *D, DecLds &lds)
     for (int i = 0; i < 16; i++) c.tm[i] = 0;
     unsigned long long tk0 = __builtin_readcyclecounter();
 #endif
-    c.need = 0; c.err = 0; c.undo_n = 0; c.careful = 1;
+    c.need = 0; c.err = 0; c.undo_n = 0; c.careful = 1; c.fast = 0; c.blk[0] = c.blk[1] = nullptr;
     c.bv[0] = c.bv[1] = 0; c.woff[0] = c.woff[1] = 64;
     c.phase = DUNI(D->phase); c.type = DUNI(D->type); c.run_size = DUNI(D->run_size); c.i = DUNI(D->i); c.copied = DUNI(D->copied); c.copied_from = DUNI(D->copied_from);
     c.out_size = DUNI(D->out_size); c.p_delta_ready = DUNI(D->p_delta_ready); c.status = DEC_RUNNING;
+    lds.hand.d_lo = (uint32_t)(uint64_t)D; lds.hand.d_hi = (uint32_t)((uint64_t)D >> 32);
+#ifdef CSCMI_TIMERS
+    for (int i = 0; i < 16; i++) lds.hand.tm[i] = 0;
+#endif
     for (uint32_t i = c.lane; i < P_COUNT; i += 64) lds.P[i] = D->probs[i];
     for (uint32_t i = c.lane; i < 122; i += 64) {
         const dgu8 *w = (const dgu8 *)D->words + i * 8;
@@ -731,8 +930,7 @@ DDEV void decode_stream(gDecState *D, DecLds &lds)
             const uint32_t type = c.type, size = c.run_size;
             uint32_t i = c.i, sctx = c.copied;   // `copied` doubles as the RLE context between launches
             if (type >= DT_DLT && !c.p_delta_ready) {
-                for (uint32_t t = c.lane; t < 256 * 256; t += 64) c.p_delta[t] = 2048;
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                d_fill_words(c.p_delta, 256 * 256, 2048);
                 c.p_delta_ready = 1;
             }
             while (i < size) {
@@ -748,8 +946,7 @@ DDEV void decode_stream(gDecState *D, DecLds &lds)
                 if (runlen) {
                     uint32_t n = runlen < size - i ? runlen : size - i;
                     uint32_t prev = DUNI((uint32_t)c.out[i - 1]);
-                    for (uint32_t t = c.lane; t < n; t += 64) c.out[i + t] = (uint8_t)prev;
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    d_fill_bytes(c.out + i, n, prev);
                     ni = i + n;
                     sctx = prev;
                 } else {
@@ -764,9 +961,9 @@ DDEV void decode_stream(gDecState *D, DecLds &lds)
         case DEC_PH_POST: {
             const uint32_t type = c.type, size = c.out_size;
             DTM_DECL;
-            if (type == DT_EXE) dinverse_e89(c, size);
-            else if (type == DT_ENGTXT) dinverse_dict(c, size);
-            else if (type >= DT_DLT) { dinverse_delta(c, size, kDltIndexD[type - DT_DLT]); dcopy2dict(c, size); }
+            if (type == DT_EXE) dinverse_e89(c.out, size);
+            else if (type == DT_ENGTXT) dinverse_dict(c.out, (dgu8 *)c.D->swap, size);
+            else if (type >= DT_DLT) { dinverse_delta(c.out, (dgu8 *)c.D->swap, size, type - DT_DLT < 4 ? type - DT_DLT + 1 : 8u); dcopy2dict(c, size); }
             else if (type == DT_BAD || type == DT_ENTROPY) dcopy2dict(c, size);
             DTM_ADD(c, 4);
             c.phase = DEC_PH_TAIL;
@@ -795,7 +992,7 @@ DDEV void decode_stream(gDecState *D, DecLds &lds)
         for (uint32_t i = c.lane; i < 65536 * 2 / 16; i += 64) dst[i] = src[i];
     }
 #ifdef CSCMI_TIMERS
-    if (c.lane == 0) { for (int i = 0; i < 16; i++) D->dbg[i] += c.tm[i]; D->dbg[7] += __builtin_readcyclecounter() - tk0; D->dbg[15]++; }
+    if (c.lane == 0) { for (int i = 0; i < 16; i++) D->dbg[i] += c.tm[i] + lds.hand.tm[i]; D->dbg[7] += __builtin_readcyclecounter() - tk0; D->dbg[15]++; }
 #endif
     if (c.lane == 0) {
         for (int i = 0; i < 2; i++) { D->taken[i] = c.taken[i]; D->rd[i] = c.rd[i]; D->fill[i] = c.fill[i]; }
@@ -808,12 +1005,10 @@ DDEV void decode_stream(gDecState *D, DecLds &lds)
     }
 }
 
-extern __shared__ __attribute__((aligned(16))) uint8_t dec_smem[];
-
 // one stream: CSCDec_Decode
 __global__ __launch_bounds__(64) void k_decode_run(DecState *D)
 {
-    decode_stream((gDecState *)D, *(DecLds *)dec_smem);
+    decode_stream((gDecState *)D, g_dec_lds);
 }
 // many independent streams (the tasks of an archive): workgroup b advances stream b until it needs input or its
 // Decompress call is complete; one stream per CU (the literal table fills most of the LDS)
@@ -822,7 +1017,7 @@ __global__ __launch_bounds__(64) void k_decode_run_multi(DecState *const *states
     // the pointer is the same in every lane; say so, or everything loaded through it is treated as per-lane data
     const uint64_t a = (uint64_t)states[blockIdx.x];
     const uint64_t u = ((uint64_t)DUNI((uint32_t)(a >> 32)) << 32) | DUNI((uint32_t)a);
-    decode_stream((gDecState *)u, *(DecLds *)dec_smem);
+    decode_stream((gDecState *)u, g_dec_lds);
 }
 
 __global__ void k_decode_init(DecState *D)
@@ -832,23 +1027,14 @@ __global__ void k_decode_init(DecState *D)
     for (uint32_t i = tid; i < P_COUNT; i += nth) D->probs[i] = 2048;
 }
 
-static hipError_t dec_lds_attr()
-{
-    static hipError_t e1 = hipFuncSetAttribute((const void *)k_decode_run, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLdsBytes);
-    static hipError_t e2 = hipFuncSetAttribute((const void *)k_decode_run_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLdsBytes);
-    return e1 != hipSuccess ? e1 : e2;
-}
-
 void launch_decode_init(DecState *D, hipStream_t st) { hipLaunchKernelGGL(k_decode_init, dim3(64), dim3(256), 0, st, D); }
 void launch_decode_run(DecState *D, hipStream_t st)
 {
-    (void)dec_lds_attr();
-    hipLaunchKernelGGL(k_decode_run, dim3(1), dim3(64), kDecLdsBytes, st, D);
+    hipLaunchKernelGGL(k_decode_run, dim3(1), dim3(64), 0, st, D);
 }
 void launch_decode_run_multi(DecState *const *states, uint32_t n, hipStream_t st)
 {
-    (void)dec_lds_attr();
-    hipLaunchKernelGGL(k_decode_run_multi, dim3(n), dim3(64), kDecLdsBytes, st, states);
+    hipLaunchKernelGGL(k_decode_run_multi, dim3(n), dim3(64), 0, st, states);
 }
 
 }  // namespace cscmi
