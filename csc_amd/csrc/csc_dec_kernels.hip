@@ -164,6 +164,7 @@ DDEV uint32_t next_byte(Dc &c, int kind)
 // all that sits on the dependency chain (rc_bit, ~12 instructions).  The probability UPDATE of the nodes a symbol
 // visited does not feed the chain (a tree visits each node at most once per symbol), so it is done afterwards by the
 // lanes that hold those nodes: one vector update + one LDS store per tree instead of one per bit (tree_update).
+DDEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 DDEV uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 
 // range / code into scalar registers: at the top of every packet (what flows around the packet loop may count as per-lane data)
@@ -174,14 +175,14 @@ DDEV uint32_t rc_bit_at(Dc &c, uint32_t p)
     if (UNLIKELY(c.range < (1u << 24))) { c.range = DUNI(c.range << 8); c.code = DUNI((c.code << 8) + next_byte(c, 1)); }
     // The chain as SCALAR instructions, spelled out: left to itself the compiler keeps range / code / the tree index in vector
     // registers (a quarter-rate v_mul_lo_u32, v_cmp + v_cndmask pairs, a v_readfirstlane before every v_readlane: rounds 1-4
-    // measured 177 cycles a binary decision).  Eight SALU operations: bound, the two differences, one compare, three selects.
+    // measured 177 cycles a binary decision).  Seven SALU operations: bound, the two differences (the second one's borrow is the
+    // bit), three selects.
     uint32_t bound, bit, r2, c2;
     asm("; rc_bit site %7\n\t"
         "s_lshr_b32 %0, %4, 12\n\t"
         "s_mul_i32 %0, %0, %6\n\t"
         "s_sub_u32 %2, %4, %0\n\t"
-        "s_sub_u32 %3, %5, %0\n\t"
-        "s_cmp_lt_u32 %5, %0\n\t"
+        "s_sub_u32 %3, %5, %0\n\t"          // SCC = the borrow = (code < bound) = the bit
         "s_cselect_b32 %2, %0, %2\n\t"
         "s_cselect_b32 %3, %5, %3\n\t"
         "s_cselect_b32 %1, 1, 0"
@@ -201,8 +202,7 @@ DDEV uint32_t rc_step(Dc &c, uint32_t p, uint32_t v)
     asm("s_lshr_b32 %0, %4, 12\n\t"
         "s_mul_i32 %0, %0, %6\n\t"
         "s_sub_u32 %2, %4, %0\n\t"
-        "s_sub_u32 %3, %5, %0\n\t"
-        "s_cmp_lt_u32 %5, %0\n\t"
+        "s_sub_u32 %3, %5, %0\n\t"          // SCC = the borrow = (code < bound) = the bit
         "s_cselect_b32 %2, %0, %2\n\t"
         "s_cselect_b32 %3, %5, %3\n\t"
         "s_addc_u32 %1, %7, %7"
@@ -213,11 +213,12 @@ DDEV uint32_t rc_step(Dc &c, uint32_t p, uint32_t v)
     c.code = c2;
     return vn;
 }
-// p += (0xFFF - p) >> 5 or p -= p >> 5; 0xFFF - p == p ^ 0xFFF for 12-bit p
+// p += (0xFFF - p) >> 5 or p -= p >> 5 (csc_dec.cpp:24-33; p is a 12-bit number)
+// as ONE expression for both bits: p + ((T - p) >> 5) with T = 4095 / 31 and an arithmetic shift -- floor((31 - p) / 32) = -(p >> 5)
 DDEV uint32_t p_update(uint32_t p, uint32_t bit)
 {
-    const uint32_t d = (p ^ (bit ? 0xFFFu : 0u)) >> 5;
-    return bit ? p + d : p - d;
+    const int32_t t = bit ? 4095 : 31;
+    return p + (uint32_t)((t - (int32_t)p) >> 5);
 }
 // ---- lane-divergent work lives OUTSIDE the packet loop's control flow --------------------------------------------------
 // Rounds 1-5 kept the whole stream context in VECTOR registers (a 215-VGPR loop with thirty v_mov phi copies at its head,
@@ -290,6 +291,20 @@ DDEV uint32_t dbit_p_at(Dc &c, uint32_t idx, uint32_t p)
     return bit;
 }
 #define dbit_p(c, idx, p) dbit_p_at<__LINE__>((c), (idx), (p))
+// A packet flag out of the gather `fl` (lane k holds flag k, read from table index `own`; k's index is idx): the update is made
+// by the lane that holds the flag -- three vector operations and a store instead of eight scalar ones, two moves and a store.
+template <int SITE>
+DDEV uint32_t dflag_at(Dc &c, uint32_t fl, uint32_t own, uint32_t k, uint32_t idx)
+{
+    const uint32_t p = rl(fl, k);
+    const uint32_t bit = rc_bit_at<SITE>(c, p);
+    if (UNLIKELY(c.careful)) journal_put(c, c.undo_n, idx, p);
+    c.undo_n++;
+    c.L->P[c.lane == k ? own : kPDump] = p_update(fl, bit);
+    return bit;
+}
+#define dflag(c, fl, own, k, idx) dflag_at<__LINE__>((c), (fl), (own), (k), (idx))
+DDEV uint32_t dflag_index(const Dc &c, uint32_t st3) { return (c.lane < 3 ? P_STATE : P_REPDIST - 3) + st3 + (c.lane < 6 ? c.lane : 5); }
 #define dbit(c, idx) dbit_p_at<__LINE__>((c), (idx), DUNI((c).L->P[(idx)]))
 
 DDEV uint32_t ddirect16(Dc &c, uint32_t len)   // coder_decode_direct, csc_dec.cpp:65-88
@@ -461,10 +476,10 @@ struct Wr { uint32_t kind, from, dist, len, byte; };     // kind 0 nothing (the 
 DDEV bool dlz_packet_head(Dc &c, uint32_t &st3, uint32_t &fl, uint32_t &lrow, uint32_t &ltop)
 {
     st3 = c.state * 3;
-    fl = c.L->P[(c.lane < 3 ? P_STATE : P_REPDIST - 3) + st3 + (c.lane < 6 ? c.lane : 5)];
+    fl = c.L->P[dflag_index(c, st3)];
     lrow = c.ctx * 256;
     ltop = c.L->plit[lrow + (c.lane & 15)];
-    return dbit_p(c, P_STATE + st3, rl(fl, 0)) == 0;
+    return dflag(c, fl, dflag_index(c, st3), 0, P_STATE + st3) == 0;
 }
 DDEV uint32_t dlz_literal(Dc &c, uint32_t lrow, uint32_t ltop)
 {
@@ -478,7 +493,8 @@ DDEV void dlz_packet_rest(Dc &c, uint32_t st3, uint32_t fl, uint32_t i, uint32_t
 {
     ni = i; end = false;
     w.kind = 0; w.from = 0; w.dist = 0; w.len = 0; w.byte = 0;
-    if (dbit_p(c, P_STATE + st3 + 1, rl(fl, 1)) == 1) {
+    const uint32_t own = dflag_index(c, st3);
+    if (dflag(c, fl, own, 1, P_STATE + st3 + 1) == 1) {
         uint32_t dist, len;
         dmatch(c, dist, len);
         if (len == 0 && dist == 64) end = true;
@@ -489,14 +505,14 @@ DDEV void dlz_packet_rest(Dc &c, uint32_t st3, uint32_t fl, uint32_t i, uint32_t
             if (from >= c.wnd_size || from + len > c.wnd_size || len + i > limit || c.wnd_pos + len > c.wnd_size) c.err = 1;
             w.kind = 2; w.from = from; w.dist = dist; w.len = len; ni = i + len;
         }
-    } else if (dbit_p(c, P_STATE + st3 + 2, rl(fl, 2)) == 0) {
+    } else if (dflag(c, fl, own, 2, P_STATE + st3 + 2) == 0) {
         c.state = (c.state * 4 + 2) & 0x3F;
         uint32_t from = c.wnd_pos > c.rep[0] ? c.wnd_pos - c.rep[0] : c.wnd_pos + c.wnd_size - c.rep[0];
         if (from > c.wnd_size) c.err = 1;   // the reference reads out of bounds here on corrupt input
         w.kind = 2; w.from = from; w.dist = c.rep[0]; w.len = 1; ni = i + 1;
     } else {
-        uint32_t kk = 2u + dbit_p(c, P_REPDIST + st3, rl(fl, 3));
-        kk = kk + kk + dbit_p(c, P_REPDIST + st3 + kk - 1, rl(fl, 3 + kk - 1));
+        uint32_t kk = 2u + dflag(c, fl, own, 3, P_REPDIST + st3);
+        kk = kk + kk + dflag(c, fl, own, 3 + kk - 1, P_REPDIST + st3 + kk - 1);
         uint32_t idx = kk & 3, len = dmatchlen_2(c) + 2;
         c.state = (c.state * 4 + 3) & 0x3F;
         if (len + i > limit) c.err = 1;
@@ -563,14 +579,34 @@ DNOINL void dlz_fast()
 #ifdef CSCMI_TIMERS
     for (int t = 0; t < 16; t++) c.tm[t] = 0;
 #endif
+    // A copy of up to 64 bytes is TWO instructions a packet apart: its load is issued when the packet is decoded, its store -- and
+    // the wait in front of it -- when the next packet needs the window or the context (a literal: the byte it is coded under; a
+    // copy: before its own load, a wavefront's memory operations are carried out in order).  The bytes wait in `pv`, one a lane;
+    // lanes >= p_n have nothing to store (their buffer offset is out of range: the hardware drops them), lane p_last holds the
+    // byte that follows as context.  With no copy pending pv is the context byte in every lane.
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)c.wnd, 0, (int)(c.wnd_size + 256u), 0x00020000);
+    uint32_t pv = c.ctx, p_n = 0, p_to = 0, p_last = 0;
+    auto flush = [&]() {
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)pv, wr, (int)(c.lane < p_n ? p_to + c.lane : 0xFFFFFFFFu), 0, 0);
+        p_n = 0;
+    };
     for (;;) {
         // the same tests as the caller's
         if (UNLIKELY(i > limit || c.wnd_pos >= c.wnd_size || c.rd[1] + kDecUndoCap / 8 + 64 > c.fill[1] || c.rd[0] + 16 > c.fill[0])) break;
         DTM_DECL;
-        uint32_t st3, fl, lrow, ltop;
+        // the packet's flags hang on the state only: the first of them is decoded while a pending copy's load is still under way
+        uint32_t st3 = c.state * 3;
+        uint32_t fl = c.L->P[dflag_index(c, st3)];
         // A run of literals is a loop of its own: nothing of a literal can fail, it moves only the coder's words, the context, the
         // state and the two positions -- the rep distances and the bit coder's words are not carried round this loop.
-        if (LIKELY(dlz_packet_head(c, st3, fl, lrow, ltop))) {
+        if (LIKELY(dflag(c, fl, dflag_index(c, st3), 0, P_STATE + st3) == 0)) {
+          c.ctx = rl(pv, p_last);
+          flush();
+          uint32_t lrow = c.ctx * 256;
+          uint32_t ltop = c.L->plit[lrow + (c.lane & 15)];
+          // the run ends with the run of the block / the window, or in front of a careful zone: one count, one comparison
+          const uint32_t n0 = umin(limit + 1 - i, c.wnd_size - c.wnd_pos), rd_stop = c.fill[1] - (kDecUndoCap / 8 + 64);
+          uint32_t n_left = n0;
           bool stop;
           do {
             LowTree lo;
@@ -583,16 +619,18 @@ DNOINL void dlz_fast()
             // loop's tests) rides on the latency of these loads
             // (volatile: the compiler would sink the flags' load behind the loop's tests, to where they are used)
             st3 = c.state * 3;
-            fl = *(volatile __attribute__((address_space(3))) uint32_t *)&c.L->P[(c.lane < 3 ? P_STATE : P_REPDIST - 3) + st3 + (c.lane < 6 ? c.lane : 5)];
+            fl = *(volatile __attribute__((address_space(3))) uint32_t *)&c.L->P[dflag_index(c, st3)];
             lrow = b * 256;
             ltop = *(volatile __attribute__((address_space(3))) uint16_t *)&c.L->plit[lrow + (c.lane & 15)];
             dbyte_low_update<1>(c, lo);
             c.wnd[c.wnd_pos] = (uint8_t)b;          // (every lane the same byte to the same place)
             c.wnd_pos++;
-            i++;
+            n_left--;
             DTM_ADD(c, 2);
-            stop = i > limit || c.wnd_pos >= c.wnd_size || c.rd[1] + kDecUndoCap / 8 + 64 > c.fill[1];
-          } while (LIKELY(!stop) && LIKELY(dbit_p(c, P_STATE + st3, rl(fl, 0)) == 0));
+            stop = n_left == 0 || c.rd[1] > rd_stop;
+          } while (LIKELY(!stop) && LIKELY(dflag(c, fl, dflag_index(c, st3), 0, P_STATE + st3) == 0));
+          i += n0 - n_left;
+          pv = c.ctx; p_last = 0;
           if (UNLIKELY(stop)) break;     // (nothing of the next packet has been decoded)
         }
         c.undo_n = 1;
@@ -600,10 +638,22 @@ DNOINL void dlz_fast()
         dlz_packet_rest(c, st3, fl, i, limit, ni, end, w);
         DTM_ADD(c, 1);
         if (UNLIKELY(((c.undo_n > kDecUndoCap ? 1u : 0u) | c.err | (end ? 1u : 0u)) != 0)) { ret = (c.err || c.undo_n > kDecUndoCap) ? 2u : 1u; break; }
-        dlz_write(c, w);
+        // the packet's copy (every kind that comes here has one)
+        flush();
+        const bool overlap = w.from < c.wnd_pos && w.from + w.len > c.wnd_pos;      // then dist = wnd_pos - from < len
+        if (LIKELY(w.len <= 64 && !overlap)) {
+            pv = __builtin_amdgcn_raw_buffer_load_b8(wr, (int)(w.from + c.lane), 0, 0);
+            p_n = w.len; p_to = c.wnd_pos; p_last = w.len - 1;
+        } else {
+            pv = dcopy_match(c, w.from, w.dist, w.len);
+            p_last = 0;
+        }
+        c.wnd_pos += w.len;
         i = ni;
         DTM_ADD(c, 2);
     }
+    c.ctx = rl(pv, p_last);
+    flush();
     H.rd[0] = c.rd[0]; H.rd[1] = c.rd[1];
     H.range = c.range; H.code = c.code; H.bc_bits = c.bc_bits; H.bc_val = c.bc_val;
     H.state = c.state; H.ctx = c.ctx; H.wnd_pos = c.wnd_pos;

@@ -8,7 +8,7 @@ divergent exit, divergent / uniform phi counts, and the divergent phis that are 
 control flow) with the lane-dependent branches found in the IR.   python3 tools/dec_uniformity.py [-v]"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "csc_amd", "csrc", "csc_dec_kernels.hip")
+SRC = os.path.join(ROOT, "csc_amd", "csrc", next((a for a in sys.argv[1:] if a.endswith(".hip")), "csc_dec_kernels.hip"))
 LLVM = "/opt/rocm/lib/llvm/bin"
 verbose = "-v" in sys.argv
 extra = [a for a in sys.argv[1:] if a.startswith("-D")]
