@@ -208,6 +208,16 @@ DEV uint64_t stage_load8(const uint32_t *stage, uint32_t byte_idx)
 // ==========================================================================================
 // output arena + coder (csc_coder.cpp, csc_memio.cpp:83-108 is finished on the host)
 
+// Lane-dependent branches and the scalars of a serial loop do not go together: the compiler's uniformity analysis makes per-lane
+// data of EVERY value that is merged in a block where the two sides of such a branch meet, and after block merging those are the
+// latches of the loops around it -- one `if (lane == 0)` in a coder loop put low / range / cache and the buffer positions into
+// vector registers and made exec-mask branches of its tests (round 5, tools/enc_uniformity.py; csc_dec_kernels.hip has the longer
+// story).  So inside such loops: every lane stores the same word to the same place, a lane with nothing to store stores to a dump
+// slot, and lane-strided loops are functions of their own.
+__device__ __noinline__ void lanes_copy16(gvec4 *d4, const gvec4 *s4, uint32_t n16)
+{
+    for (uint32_t i = threadIdx.x & 63u; i < n16; i += 64) d4[i] = s4[i];
+}
 // hand a finished RC/BC buffer to the host: header + 16-byte-lane copy
 DEV void emit_block(Sc &c, uint32_t kind, const gu8 *buf, uint32_t size)
 {
@@ -215,11 +225,8 @@ DEV void emit_block(Sc &c, uint32_t kind, const gu8 *buf, uint32_t size)
     if (c.arena_used + need > c.arena_cap) { c.error = ERR_ARENA_FULL; return; }
     gu8 *dst = c.arena + c.arena_used;
     wave_fence();   // the byte stores into buf came from uniform code; the copy below is per-lane
-    if (c.lane == 0) { ((gu32 *)dst)[0] = kind; ((gu32 *)dst)[1] = size; }
-    const gvec4 *s4 = (const gvec4 *)buf;
-    gvec4 *d4 = (gvec4 *)(dst + 16);
-    uint32_t n16 = (size + 15) >> 4;
-    for (uint32_t i = c.lane; i < n16; i += 64) d4[i] = s4[i];
+    ((gu32 *)dst)[0] = kind; ((gu32 *)dst)[1] = size;       // (every lane the same words)
+    lanes_copy16((gvec4 *)(dst + 16), (const gvec4 *)buf, (size + 15) >> 4);
     c.arena_used += need;
 }
 
@@ -232,6 +239,7 @@ DEV void emit_block(Sc &c, uint32_t kind, const gu8 *buf, uint32_t size)
 //   0x20000000                          Coder::Flush
 // in coding order; the coder wavefront owns low / range / cache / the two block buffers and the output arena.
 constexpr uint32_t kCoderQ = 4096;
+constexpr uint32_t kPDumpE = P_COUNT + 3;     // EncLds::P has four words of slack: where lanes with nothing to store store
 struct CoderQ {
     uint32_t pub, tail, done, pad;
     uint32_t e[kCoderQ];
@@ -271,8 +279,10 @@ DEV void q_push_bits(Sc &c, uint32_t pold, uint32_t bit, uint32_t n, uint32_t fr
         q_publish(c);
         c.q_room = umin(kCoderQ - 64u - q_wait_room(c, 128u), 256u);
     }
+    // (no branch: the lanes that hold no decision write to the entry 63 behind the head -- q_room always leaves 64 entries spare,
+    // and every entry is written again before the head passes it)
     const uint32_t k = c.lane - from;
-    if (k < n) c.Q->e[(c.q_head + k) & (kCoderQ - 1)] = 0x80000000u | (bit ? 0x1000u : 0u) | pold;
+    c.Q->e[(c.q_head + (k < n ? k : 63u)) & (kCoderQ - 1)] = 0x80000000u | (bit ? 0x1000u : 0u) | pold;
     c.q_head += n; c.q_room -= n;
 }
 
@@ -430,12 +440,13 @@ DEV void encode_literal(Sc &c, uint32_t sym)
         const uint32_t k = (c.lane - 1u) & 7u;
         const uint32_t idx = cc >> (8 - k), bit = c.lane == 0 ? 0u : (cc >> (7 - k)) & 1;
         const uint32_t fidx = P_STATE + c.state * 3;
-        uint32_t pold = 0;
-        if (c.lane == 0) pold = c.L->P[fidx];
-        else if (c.lane < 9) pold = row[idx];
+        // (loads by every lane, stores to a dump slot from the lanes that hold nothing: no lane-dependent branch, see emit_block)
+        const uint32_t pf = c.L->P[fidx], pr = row[idx];
+        const uint32_t pold = c.lane == 0 ? pf : c.lane < 9 ? pr : 0u;
         const uint32_t pnew = p_update(bit, pold);
-        if (c.lane == 0) c.L->P[fidx] = pnew;
-        else if (c.lane < 9) row[idx] = pnew;
+        c.L->P[c.lane == 0 ? fidx : kPDumpE] = pnew;
+        gu32 *const dst = (c.lane - 1u < 8u) ? row + idx : (gu32 *)c.S->pf_sink + c.lane;
+        *dst = pnew;
         q_push_bits(c, pold, bit, 9);
         c.state = (c.state * 4) & 0x3F;
         c.ctx = sym;
