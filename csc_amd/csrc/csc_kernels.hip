@@ -736,6 +736,9 @@ DEV void compress_rle(Sc &c, const gu8 *src, uint32_t size)
     }
 }
 
+// level-5 form (csc_kernels_bt.inc): the finder wavefront (bt_finder) was measured slower; kept for the record, not dispatched
+constexpr bool kBtFinder = false;
+constexpr uint32_t kBtThreads = kBtFinder ? 448 : 256;
 DEV void sc_load_regs(Sc &c, EncState *S, EncLds *L);   // csc_kernels_blocks.inc: the register part of a context (the roles' own functions build theirs with it)
 #include "csc_kernels_mf.inc"
 #include "csc_kernels_lz.inc"
