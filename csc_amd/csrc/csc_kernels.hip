@@ -176,6 +176,32 @@ DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 // a 64-bit value / a pointer that is the same in every lane, told to the compiler (two v_readfirstlane)
 DEV uint64_t uni64(uint64_t v) { return ((uint64_t)UNI((uint32_t)(v >> 32)) << 32) | UNI((uint32_t)v); }
 template <class T> DEV T *uni_gptr(T *p) { return (T *)(uintptr_t)uni64((uint64_t)(uintptr_t)p); }
+// Every scalar of the context through v_readfirstlane: whatever a lane-dependent branch somewhere upstream (a filter's lane-strided
+// loop, the block walk) has made "per-lane data" in the compiler's eyes is wave-uniform again from here on.  The serial loops
+// call it at their head (a sub-block, a way out): some seventy VALU moves against thousands of instructions -- and everything
+// computed from these values inside the loop stays on the scalar unit (see emit_block).  Per-lane fields (cand_*_v, pr_*, gm*) are
+// left alone.
+DEV void sc_uniform(Sc &c)
+{
+    c.S = uni_gptr(c.S); c.wnd = uni_gptr(c.wnd); c.wnd_size = UNI(c.wnd_size); c.vld_rge = UNI(c.vld_rge);
+    c.ht2 = uni_gptr(c.ht2); c.ht3 = uni_gptr(c.ht3); c.ht6 = uni_gptr(c.ht6); c.bt_head = uni_gptr(c.bt_head); c.bt_nodes = uni_gptr(c.bt_nodes);
+    c.p_lit = uni_gptr(c.p_lit); c.p_delta = uni_gptr(c.p_delta); c.mfbuf = uni_gptr(c.mfbuf);
+    c.ht6_off = UNI(c.ht6_off); c.bth_off = UNI(c.bth_off);
+    c.ht_bits = UNI(c.ht_bits); c.ht_width = UNI(c.ht_width); c.ht_low = UNI(c.ht_low); c.ht_cyc = UNI(c.ht_cyc);
+    c.bt_bits = UNI(c.bt_bits); c.bt_size = UNI(c.bt_size); c.bt_cyc = UNI(c.bt_cyc); c.good_len = UNI(c.good_len);
+    c.lz_good_len = UNI(c.lz_good_len); c.lz_bt_cyc = UNI(c.lz_bt_cyc); c.lz_ht_cyc = UNI(c.lz_ht_cyc);
+    c.bt_pos = UNI(c.bt_pos); c.pos = UNI(c.pos); c.wnd_curpos = UNI(c.wnd_curpos);
+    c.state = UNI(c.state); c.ctx = UNI(c.ctx); c.lp_rebuild_int = UNI(c.lp_rebuild_int);
+    c.rc_low = uni64(c.rc_low); c.rc_range = UNI(c.rc_range); c.rc_cache = UNI(c.rc_cache); c.rc_cachesize = UNI(c.rc_cachesize);
+    c.rc_size = UNI(c.rc_size); c.bc_size = UNI(c.bc_size); c.bc_curbits = UNI(c.bc_curbits); c.bc_curval = UNI(c.bc_curval); c.bsize = UNI(c.bsize);
+    c.rc_buf = uni_gptr(c.rc_buf); c.bc_buf = uni_gptr(c.bc_buf); c.arena = uni_gptr(c.arena); c.swapbuf = uni_gptr(c.swapbuf);
+    c.arena_used = UNI(c.arena_used); c.arena_cap = UNI(c.arena_cap); c.error = UNI(c.error);
+    c.stage_base = UNI(c.stage_base); c.stage_end = UNI(c.stage_end);
+    c.wv = UNI(c.wv); c.dp_seq = UNI(c.dp_seq); c.dp_idle = UNI(c.dp_idle); c.dp_seq_seen = UNI(c.dp_seq_seen);
+    c.st_find = UNI(c.st_find); c.st_slide = UNI(c.st_slide); c.st_bt = UNI(c.st_bt); c.st_lit = UNI(c.st_lit); c.st_match = UNI(c.st_match);
+    c.q_head = UNI(c.q_head); c.q_room = UNI(c.q_room);
+}
+
 DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 DEV uint32_t rdlane(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 // write a uniform value into one lane of a per-lane register (v_cmp + v_cndmask)
@@ -217,6 +243,19 @@ DEV uint64_t stage_load8(const uint32_t *stage, uint32_t byte_idx)
 __device__ __noinline__ void lanes_copy16(gvec4 *d4, const gvec4 *s4, uint32_t n16)
 {
     for (uint32_t i = threadIdx.x & 63u; i < n16; i += 64) d4[i] = s4[i];
+}
+__device__ __noinline__ void lanes_copy8(gu8 *dst, const gu8 *src, uint32_t n)
+{
+    for (uint32_t t = threadIdx.x & 63u; t < n; t += 64) dst[t] = src[t];
+}
+__device__ __noinline__ void lanes_fill32(gu32 *dst, uint32_t n, uint32_t v)
+{
+    for (uint32_t t = threadIdx.x & 63u; t < n; t += 64) dst[t] = v;
+}
+// bytes [first, end) of the sub-block's LDS stage from the window (src[t] is the byte of stage position t)
+__device__ __noinline__ void lanes_stage(uint8_t *sb, const gu8 *src, uint32_t first, uint32_t end)
+{
+    for (uint32_t t = first + (threadIdx.x & 63u); t < end; t += 64) sb[t] = src[t];
 }
 // hand a finished RC/BC buffer to the host: header + 16-byte-lane copy
 DEV void emit_block(Sc &c, uint32_t kind, const gu8 *buf, uint32_t size)
@@ -423,7 +462,7 @@ DEV void encode_byte_tree(Sc &c, gu32 *row, uint32_t sym)
     uint32_t k = c.lane & 7;
     uint32_t idx = cc >> (8 - k), bit = (cc >> (7 - k)) & 1;
     uint32_t pold = row[idx];
-    if (c.lane < 8) row[idx] = p_update(bit, pold);
+    *(c.lane < 8 ? row + idx : (gu32 *)c.S->pf_sink + c.lane) = p_update(bit, pold);      // (lanes 8-63 to the dump: no lane-dependent branch)
 #pragma unroll
     for (int j = 0; j < 8; j++) rc_code(c, (cc >> (7 - j)) & 1, rdlane(pold, j));
 }
@@ -459,7 +498,7 @@ DEV void encode_literal(Sc &c, uint32_t sym)
     enc_bit_lds(c, 0, P_STATE + c.state * 3);
     c.state = (c.state * 4) & 0x3F;
     c.ctx = sym;
-    if (c.lane < 8) row[idx] = p_update(bit, pold);
+    *(c.lane < 8 ? row + idx : (gu32 *)c.S->pf_sink + c.lane) = p_update(bit, pold);      // (lanes 8-63 to the dump: no lane-dependent branch)
 #pragma unroll
     for (int j = 0; j < 8; j++) rc_code(c, (cc >> (7 - j)) & 1, rdlane(pold, j));
     c.st_lit++;
@@ -516,9 +555,12 @@ DEV void dec_matchlen_1(const Sc &c, Decisions &d, uint32_t len)
 // gather + update + scatter; returns the probabilities as they were
 DEV uint32_t dec_apply(Sc &c, const Decisions &d)
 {
-    uint32_t p = 0;
-    if (c.lane < d.n) { p = c.L->P[d.idx]; c.L->P[d.idx] = p_update(d.bit, p); }
-    return p;
+    // (gather by every lane, scatter to the dump slot from the lanes that hold no decision: no lane-dependent branch)
+    const bool on = c.lane < d.n;
+    const uint32_t i = on ? d.idx : kPDumpE;
+    const uint32_t p = c.L->P[i];
+    c.L->P[i] = p_update(d.bit, p);
+    return on ? p : 0u;
 }
 // range-code decisions [0, to) from registers (static lane numbers), and the four of a distance's low-bits tree
 DEV void dec_code(Sc &c, uint32_t pold, uint64_t bits, uint32_t to)
@@ -654,12 +696,13 @@ DEV uint32_t match_dist_price(const Sc &c, uint32_t fs, uint32_t dist)   // csc_
     return lds_price(c, 1, P_STATE + fs * 3) + lds_price(c, 1, P_STATE + fs * 3 + 1) + (l > 2 ? l + 2 : 2) * 128;
 }
 
-// Model::len_price_rebuild, csc_model.cpp:234-270 -- one length per lane
-DEV void len_price_rebuild(Sc &c)
+// Model::len_price_rebuild, csc_model.cpp:234-270 -- one length per lane.  A function of its own: its per-lane loops must not meet
+// the callers' scalars (see emit_block); it runs once in 4096 price calls.
+__device__ __noinline__ void len_price_rebuild_lanes(EncLds *L)
 {
-    EncLds *L = c.L;
-    if (c.lane < 32) {
-        uint32_t len = c.lane, ret = 0, cc, base;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (lane < 32) {
+        uint32_t len = lane, ret = 0, cc, base;
         uint32_t s0 = L->P[P_LEN_SLOT], s1 = L->P[P_LEN_SLOT + 1];
         if (len < 16) {
             if (len < 8) { ret += L->p2b[(4096u - s0) >> 3]; base = P_LEN_X1; }
@@ -680,8 +723,12 @@ DEV void len_price_rebuild(Sc &c)
                 cc <<= 1;
             } while (cc < 0x4000);
         }
-        L->len_price[c.lane] = ret;
+        L->len_price[lane] = ret;
     }
+}
+DEV void len_price_rebuild(Sc &c)
+{
+    len_price_rebuild_lanes(c.L);
     c.lp_rebuild_int = 4096;
 }
 
@@ -711,7 +758,7 @@ DEV void compress_rle(Sc &c, const gu8 *src, uint32_t size)
     uint32_t sctx = 0;
     encode_int(c, size);
     if (!UNI(S->p_delta_ready)) {
-        for (uint32_t i = c.lane; i < 256 * 256; i += 64) c.p_delta[i] = 2048;
+        lanes_fill32(c.p_delta, 256 * 256, 2048);
         wave_fence();
         S->p_delta_ready = 1;
     }
