@@ -1,6 +1,6 @@
 # the round's bench lines once more on the frozen library, with roofline.traffic from profiles/pmc_traffic.json (gpurun -- bash tools/bench_lines.sh <tag>)
 cd $GRAFT_REPO_ROOT
-T=${1:-r04}
+T=${1:-r05}
 python bench.py > gpurun_out/${T}_a_bench.json 2> gpurun_out/${T}_a_bench.err
 python bench.py --config silesia --steps 4 --warmup 1 > gpurun_out/${T}_m5_bench.json 2> gpurun_out/${T}_m5_bench.err
 python bench.py --config mix5 --steps 4 --warmup 1 > gpurun_out/${T}_m2_bench.json 2> gpurun_out/${T}_m2_bench.err

@@ -36,8 +36,8 @@ if PAIR:
     names = ["M pre:tables", "M pre:wait labels", "M pre:reps+lit", "M wait decision", "M crit", "M post:pricing", "M post:relax", "M way out",
              "H pre:tables", "H pre:wait labels", "H pre:reps+lit", "H wait decision", "H crit", "H post:pricing", "H post:relax", "-"]
 if level == 5 and not PAIR:      # the inserter form (csc_kernels_bt.inc): parser wavefront 0-7, inserter wavefront 8-11
-    names = ["P wait for the finder's answer", "P read the answer", "P - (search: see F)", "P pricing", "P dp:statefix", "P dp:litprice+relax", "P dp:exit(backward+encode)", "P wait for the post wavefront",
-             "I gather + same-key", "I HT2/HT3/far lengths", "I descents", "I skip events (undo + replay)", "Q pricing", "Q relaxation", "F requests (hit: a look; miss: the search)", "F searches ahead"]
+    names = ["P wait for the record", "P record + rep compare", "P acceptance", "P pricing", "P dp:statefix", "P dp:litprice+relax", "P dp:exit(backward+encode)", "P wait for the post wavefront",
+             "I gather + same-key", "I HT2/HT3/far lengths", "I descents", "I skip events (undo + replay)", "Q pricing", "Q relaxation", "-", "-"]      # (slots 14 / 15: the finder wavefront of the round-5 experiment, not dispatched)
 if level in (1, 2) and not PAIR:   # the inserter form of the lazy levels (csc_kernels_hp.inc): parser wavefront 0-11, inserter wavefront 12-15
     names = ["P wait for the record", "P record + rep compare", "P acceptance", "-", "-", "-", "-", "P slide check / event", "dict filter", "window memcpy",
              "P symbol -> token", "P FindMatch pick", "I gather + same-key + stores", "I lengths + record", "-", "I events (undo / exact slide)"]
