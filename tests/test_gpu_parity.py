@@ -468,6 +468,43 @@ def test_device_decoder_on_oracle_streams(prod, orc, zalloc, name, level):
     assert prod.decode(s, max_read=1000) == orc.decode(s, alloc=zalloc, max_read=1000)
 
 
+@pytest.mark.parametrize("level", [1, 3, 5])
+def test_device_decoder_copy_shapes_and_literal_runs(prod, orc, zalloc, level):
+    """Round 5: the decoder's packets outside the careful zones run in `dlz_fast` -- copies of up to 64 bytes deferred by a packet
+    (buffer instructions, lanes behind the end masked by an out-of-range offset), longer and overlapping ones through d_copy_match,
+    runs of literals in a loop of their own.  Data built for exactly these shapes: matches of every length around 64 at every small
+    period (overlap: distance < length), matches right behind each other, single literals between matches, long literal runs, and
+    enough of it to cross several RC blocks (careful zones at their ends).  Oracle-encoded, device-decoded, byte for byte."""
+    import random
+    rnd = random.Random(0xC5C0D + level)
+    out = bytearray(rnd.randbytes(4096))
+    while len(out) < 1_500_000:
+        k = rnd.randrange(7)
+        if k == 0:                       # an overlapping copy: period 1..70, length around 64
+            per, n = rnd.randrange(1, 71), rnd.choice([2, 3, 31, 62, 63, 64, 65, 66, 127, 128, 129, 300])
+            seed = out[-per:]
+            out += bytes(seed[i % per] for i in range(n))
+        elif k in (1, 2):                # a far copy of a length around 64, maybe a second one right behind it
+            for _ in range(rnd.randrange(1, 3)):
+                n = rnd.choice([2, 3, 4, 17, 60, 63, 64, 65, 70, 143, 144, 145, 400])
+                a = rnd.randrange(0, len(out) - n)
+                out += out[a:a + n]
+        elif k == 3:                     # one literal between two copies
+            out.append(rnd.randrange(256))
+        elif k == 4:                     # a run of literals (incompressible)
+            out += rnd.randbytes(rnd.choice([1, 2, 5, 40, 700, 5000]))
+        elif k == 5:                     # text-like: literals under few contexts
+            out += bytes(rnd.choice(b"etaoin shrdlu") for _ in range(rnd.randrange(1, 200)))
+        else:                            # a repeat of the last distance (rep0) after a literal
+            n = rnd.randrange(2, 40)
+            d = rnd.randrange(1, 2000)
+            out += out[-d:-d + n] if d > n else out[-d:] * (n // d + 1)
+    data = bytes(out[:1_500_000])
+    rc, s = orc.encode(data, level, 1 << 20, alloc=zalloc)
+    assert rc == 0
+    assert prod.decode(s) == (0, data)
+
+
 def test_decoder_error_paths(prod, orc, zalloc):
     from csc_amd.capi import BytesWriter
     data = cases.build(cases.STREAM_CASES["mix_types"][0])
