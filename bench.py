@@ -35,6 +35,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+D4_MULTI_MAX = 768                  # csc_kernels_dp4.inc kD4MultiMax: launches of up to this many level-3 streams take the pipeline form (tests/test_product_host.py keeps the two equal)
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
 ALG_BYTES = {1: 33.0, 2: 96.0, 3: 42.0, 4: 96.0}   # B_HT(w) per input byte (+ ratio r)
 CONFIGS = {   # BASELINE.json configs -> (corpus name, level, dict)
@@ -594,7 +595,7 @@ def run_split(args, R, lib, src, level, dict_size, split, steps, warmup, with_cp
         nl = max(1, s1.encode_launches - s0.encode_launches)
         line["roofline"] = roofline(level, ratio, s1.encode_launches - s0.encode_launches, s1.encode_kernel_ms - s0.encode_kernel_ms,
                                     (s1.input_bytes - s0.input_bytes), # (which form a launch takes: csc_kernels_blocks.inc, launch_encode_runs_multi -- the pipeline form holds one stream a CU)
-                                    ("k_encode_runs_multi_dp4" if S <= 256 else "k_encode_runs_multi<3,true> (one parse wavefront a stream, four streams a CU)") if level == 3 else "k_encode_runs_multi*",
+                                    ("k_encode_runs_multi_dp4" if S <= D4_MULTI_MAX else "k_encode_runs_multi_one (one parse wavefront a stream, four streams a CU)") if level == 3 else "k_encode_runs_multi*",
                                     f"rank 0's GPU: {S} streams per launch, one workgroup each; per-launch time from HIP events on the launch stream",
                                     traffic_from_profile(f"m{level}_d{args.dict}_p{split}", (s1.input_bytes - s0.input_bytes) / nl) if R.world == 1 else (None, "PMC passes are recorded for N = 1"))
         line["tasks_per_rank"] = [len(a) for a in tasks.assign(slices, R.world)]
@@ -768,6 +769,32 @@ def run_tree(args, R, spec):
     return line
 
 
+def summary_of(line):
+    """A compact object (<= 600 characters) emitted as the LAST key of the JSON line: a record that keeps only the tail of the line
+    still shows the headline, the other single-GPU BASELINE configs (configs[2], the configs[4] task), the -p8 point and the
+    many-stream legs.  Per entry: [MB/s, roofline frac, reference MB/s on the host cores (or None), bit-exact flag]."""
+    def ent(o):
+        if not isinstance(o, dict) or "value" not in o:
+            return None
+        cb = o.get("cpu_baseline") if isinstance(o.get("cpu_baseline"), dict) else {}
+        ok = o.get("bit_exact_vs_cpu_baseline", o.get("bit_exact_vs_reference", o.get("bit_exact_vs_reference_digest")))
+        fr = (o.get("roofline") or {}).get("frac", o.get("hbm_roofline_frac"))
+        return [o["value"], fr, cb.get("value"), ok]
+    out = {"fmt": "[MB/s, hbm_frac, cpu_ref_MB/s, bit_exact]", "headline": ent(line)}
+    for k, v in (line.get("other_configs") or {}).items():
+        lvl = "m5" if "_m5_" in k or k == "silesia" else "m2" if "_m2_" in k or k == "mix5" else k[:8]
+        out[lvl] = ent(v) if ent(v) else str(v)[:60]
+    if "p8_on_one_gpu" in line:
+        out["p8"] = ent(line["p8_on_one_gpu"])
+    ms = line.get("multi_stream")
+    if isinstance(ms, list):
+        for m in ms:
+            out[f"p{m.get('streams')}"] = ent(m)
+            if isinstance(m.get("decode"), dict):
+                out[f"p{m.get('streams')}_dec"] = [m["decode"].get("value"), m["decode"].get("roundtrip_ok")]
+    return out
+
+
 def csc_props_for(level, dict_size):
     import csc_amd
     p = csc_amd.load().props_init(dict_size, level)
@@ -846,12 +873,14 @@ def main():
                 for oc in ("silesia", "mix5"):
                     try:
                         line["other_configs"][f"{CONFIGS[oc][0]}_m{CONFIGS[oc][1]}_d{CONFIGS[oc][2]}"] = other_config(args, R, lib, oc)
-                    except BaseException as e:          # never lose the headline to an extra (SystemExit included)
+                    except (Exception, SystemExit) as e:          # never lose the headline to an extra (SystemExit included; Ctrl-C still ends the run)
                         line["other_configs"][oc] = {"error": repr(e)[:300]}
             if args.multi_streams:
                 # extra field, not `value`: every task of the -p<S> split at once on this one GPU
                 line.update(multi_stream_job(lib, src, [int(x) for x in args.multi_streams.split(",")], level, dict_size))
     if R.rank == 0:
+        line.pop("summary", None)
+        line["summary"] = summary_of(line)          # LAST in the line: what a reader of only the line's tail must see
         print(json.dumps(line), flush=True)
     R.done()
 

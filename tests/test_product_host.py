@@ -91,3 +91,32 @@ def test_product_never_touches_the_oracle():
                 assert "liborc" not in txt and "oracle/" not in txt.replace("oracle/_ref", "").replace("`oracle/`", ""), f
     out = subprocess.run(["ldd", os.path.join(ROOT, "csc_amd", "libcsc_mi355x.so")], capture_output=True, text=True).stdout
     assert "liborc" not in out and "libcsc_ref" not in out and "libamdhip64" in out
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_names_the_kernel_form_the_library_launches():
+    """bench.py labels a split's dominant kernel from the same threshold launch_encode_runs_multi uses (round 5 advice)"""
+    src = open(os.path.join(ROOT, "csc_amd", "csrc", "csc_kernels_dp4.inc")).read()
+    k = int(re.search(r"constexpr uint32_t kD4MultiMax = (\d+);", src).group(1))
+    assert _bench_module().D4_MULTI_MAX == k
+
+
+def test_bench_summary_is_compact_and_carries_the_other_configs():
+    """the `summary` object bench.py emits LAST: <= 600 characters, with configs[2] / configs[4] / -p8 / many-stream values"""
+    b = _bench_module()
+    line = {"value": 2.2, "roofline": {"frac": 1.1e-5}, "cpu_baseline": {"value": 8.0}, "bit_exact_vs_cpu_baseline": True,
+            "other_configs": {"silesia.tar_m5_d256m": {"value": 0.57, "roofline": {"frac": 9e-6}, "cpu_baseline": {"value": 4.5}, "bit_exact_vs_cpu_baseline": True},
+                              "mix5_m2_d1024m": {"value": 2.6, "roofline": {"frac": 3e-5}, "cpu_baseline": {"value": 8.0}, "bit_exact_vs_cpu_baseline": True}},
+            "p8_on_one_gpu": {"value": 17.1, "roofline": {"frac": 9e-5}, "cpu_baseline": {"value": 51.6}, "bit_exact_vs_reference": True},
+            "multi_stream": [{"streams": 127, "value": 255.0, "hbm_roofline_frac": 1.3e-3, "bit_exact_vs_reference_digest": True, "decode": {"value": 480.0, "roundtrip_ok": True}},
+                             {"streams": 954, "value": 465.0, "hbm_roofline_frac": 2.4e-3, "bit_exact_vs_reference_digest": True, "decode": {"value": 670.0, "roundtrip_ok": True}}]}
+    s = b.summary_of(line)
+    assert len(json.dumps(s)) <= 600
+    assert s["m5"] == [0.57, 9e-6, 4.5, True] and s["m2"][0] == 2.6 and s["p8"][0] == 17.1 and s["p954"][0] == 465.0 and s["p954_dec"] == [670.0, True]
