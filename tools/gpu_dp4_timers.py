@@ -54,8 +54,8 @@ if tr[15]:
 
 if tr[15]:
     nw = tr[15]
-    print(f"    spine per window ({nw} windows, {st.find/nw:.1f} nodes each): prologue {16*tr[24]/nw:.0f}, until label 1 is out {16*tr[25]/nw:.0f}, "
-          f"poll waits {16*tr[26]/nw:.0f}, general steps {16*tr[27]/nw:.0f} ({tr[28]/nw:.2f} of them, {16*tr[27]/max(1,tr[28]):.0f} each), last iteration {16*tr[29]/nw:.0f}, epilogue {16*tr[30]/nw:.0f}, loop total {16*tr[13]/nw:.0f}")
+    print(f"    spine per window ({nw} windows, {st.find/nw:.1f} nodes each): prologue {16*tr[24]/nw:.0f}, first run of straight-line steps (loop start -> the outer loop's next entry with k >= 1: normally the 8 nodes whose literal prices the spine computed itself) {16*tr[25]/nw:.0f}, "
+          f"poll waits {16*tr[26]/nw:.0f}, general steps {16*tr[27]/nw:.0f} ({tr[28]/nw:.2f} of them, {16*tr[27]/max(1,tr[28]):.0f} each), last run of straight-line steps (the outer loop's last entry -> loop end) {16*tr[29]/nw:.0f}, epilogue {16*tr[30]/nw:.0f}, loop total {16*tr[13]/nw:.0f}")
     for i, n in enumerate(names[:8]):
         if tm[i]: print(f"    per window: {n:34s} {tm[i]/nw:8.0f}")
 

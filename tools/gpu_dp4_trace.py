@@ -24,7 +24,12 @@ for win in [int(a) for a in sys.argv[1:]] or [3000]:
     rows = [r for r in rows if r[0] or r[4]]
     if not rows: print(f"window {win}: nothing"); continue
     t0 = min(v for r in rows for v in (r[0], r[4]) if v)
-    print(f"window {win}: {len(rows)} nodes.  spine: top, poll begins, poll ends, label k+1 out (or general step ends) | edge: top, label seen, done, path (1 straight 2 rep 3 general)")
+    print(f"window {win}: {len(rows)} nodes.  spine (straight-line step of node k): step top, re-poll ended (- = the edges were not late), label k+1 out, own edge won | edge (node k): record looked at, label k seen, done, path (1 straight 2 rep 3 general) | step length, label k out -> edge sees it, edge work, edge done -> the step that needs it begins")
     f = lambda v: f"{v - t0:7d}" if v else "      -"
     for k, r in enumerate(rows):
-        print(f"{k:3d}  {f(r[0])} {f(r[8])} {f(r[1])} {f(r[2])} {f(r[3])} | {f(r[4])} {f(r[5])} {f(r[6])} {r[7]}")
+        step = r[2] - r[0] if r[2] and r[0] else 0
+        prev_out = rows[k - 1][2] if k else 0
+        notice = r[5] - prev_out if r[5] and prev_out else 0
+        work = r[6] - r[5] if r[6] and r[5] else 0
+        slack = rows[k + 1][0] - r[6] if k + 1 < len(rows) and rows[k + 1][0] and r[6] else 0
+        print(f"{k:3d}  {f(r[0])} {f(r[1])} {f(r[2])} {r[8]} | {f(r[4])} {f(r[5])} {f(r[6])} {r[7]} | {step:5d} {notice:5d} {work:5d} {slack:6d}")
