@@ -55,9 +55,15 @@ if tr[15]:
 if tr[15]:
     nw = tr[15]
     print(f"    spine per window ({nw} windows, {st.find/nw:.1f} nodes each): prologue {16*tr[24]/nw:.0f}, first run of straight-line steps (loop start -> the outer loop's next entry with k >= 1: normally the 8 nodes whose literal prices the spine computed itself) {16*tr[25]/nw:.0f}, "
-          f"poll waits {16*tr[26]/nw:.0f}, general steps {16*tr[27]/nw:.0f} ({tr[28]/nw:.2f} of them, {16*tr[27]/max(1,tr[28]):.0f} each), last run of straight-line steps (the outer loop's last entry -> loop end) {16*tr[29]/nw:.0f}, epilogue {16*tr[30]/nw:.0f}, loop total {16*tr[13]/nw:.0f}")
+          f"between runs of steps (ids, literal horizon) {16*tr[26]/nw:.0f} (ids taken over {tr[33]}, d5_refresh_ids called {tr[34]}), general steps {16*tr[27]/nw:.0f} ({tr[28]/nw:.2f} of them, {16*tr[27]/max(1,tr[28]):.0f} each), last run of straight-line steps (the outer loop's last entry -> loop end) {16*tr[29]/nw:.0f}, epilogue {16*tr[30]/nw:.0f}, loop total {16*tr[13]/nw:.0f}")
     for i, n in enumerate(names[:8]):
         if tm[i]: print(f"    per window: {n:34s} {tm[i]/nw:8.0f}")
 
+if tr[15] and any(tr[36:40]):
+    print(f"    edge wavefronts' nodes by path: straight {tr[36]}, rep0 the only rep candidate {tr[39]}, several rep candidates {tr[37]}, general {tr[38]}")
+
+if tr[15] and any(tr[0:5]):
+    print(f"    edge wavefronts' general nodes because: record not there yet {tr[0]} (waited {16*tr[1]/max(1,tr[0]):.0f} cycles each), refresh bits in the label {tr[2]}, a rep mask that cannot answer {tr[3]}, other (several reps incl. one the masks cannot give, good_len) {tr[4]}")
+
 if tr[15] and any(tr[32:36]):
-    print(f"    straight line left because: mask too old / based ahead {tr[32]}, mask's last bit {tr[33]}, straddles position == distance {tr[34]}, refresh zone {tr[35]}   (general steps in all: {tr[28]})")
+    print(f"    straight-line steps left for a general step because: equality bits that cannot answer (mask too old / based ahead / straddling) {tr[32]}, refresh zone {tr[35]}   (general steps in all: {tr[28]})")
