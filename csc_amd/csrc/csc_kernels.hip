@@ -166,7 +166,15 @@ struct Sc {
 #define TM_DECL unsigned long long tm__ = __builtin_readcyclecounter()
 #define TM_ADD(c, k) do { unsigned long long n__ = __builtin_readcyclecounter(); (c).tm[k] += n__ - tm__; tm__ = n__; } while (0)
 #define TM_RESET tm__ = __builtin_readcyclecounter()
+// (-DCSCMI_TIMERS_FINE on top: stamps per packet / per DP node as well -- some hundred cycles a node of their own, which is why the default development build
+// leaves them out: its sections are per window, a dozen s_memtime in ~80 k cycles, and its speed is the product's to a per cent or two)
+#ifdef CSCMI_TIMERS_FINE
+#define TMF_ADD(c, k) TM_ADD(c, k)
 #else
+#define TMF_ADD(c, k) do {} while (0)
+#endif
+#else
+#define TMF_ADD(c, k) do {} while (0)
 #define TM_DECL do {} while (0)
 #define TM_ADD(c, k) do {} while (0)
 #define TM_RESET do {} while (0)
