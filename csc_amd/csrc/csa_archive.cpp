@@ -686,20 +686,24 @@ int encode_tasks(std::vector<Task> &tasks, const EmitFn &emit, const CSAOptions 
             bool more = false;
             for (uint32_t i : live) more = more || !fin[i];
             if (readahead && more) {
-                reader = std::thread([&]() {
+                // (nothing may leave the lambda by exception: it would cross the C ABI as std::terminate -- a failed allocation in the reader becomes READ_ERROR for its stream)
+                auto body = [&]() {
                     (void)hipSetDevice(device);
                     for (uint32_t i : live) {
                         Slot &s = slots[i];
                         if (fin[i]) continue;
-                        const int64_t n = fill_chunk(J, J.lane[1], i, s, s.d_chunk2);
+                        int64_t n;
+                        try { n = fill_chunk(J, J.lane[1], i, s, s.d_chunk2); } catch (...) { n = -1; }
                         s.pre_n = n < 0 ? (n == -1 ? (int64_t)READ_ERROR : n) : n;
                         if (n < 0) break;
                     }
-                });
+                };
+                try { reader = std::thread(body); } catch (...) { body(); }          // (no thread to be had: read ahead on this one, before the launch)
             }
             rc = CSCMI_EncodeDeviceChunkBatch((int)hs.size(), hs.data(), ptrs.data(), sizes.data());
+            const double t1 = now_s();
             if (reader.joinable()) reader.join();
-            if (st) st->seconds_encode += now_s() - t0;
+            if (st) { st->seconds_encode += t1 - t0; st->seconds_io += now_s() - t1; }      // (time spent waiting for the reader after the launch is I/O, not encode)
             if (rc) break;
         }
 
@@ -1257,7 +1261,7 @@ int finish_archive(int fd, uint64_t arc_end, AddPlan &P, const BlockIndex &abind
 }
 
 // shard blob: what one rank hands to the rank that writes the archive.  All fields little-endian.
-//   u32 'CSAS' | u32 tasks in the whole plan | u32 tasks in this blob
+//   u32 'CSAS' | u32 tasks in the whole plan | u32 tasks in this blob | u32 hash of the task -> rank deal this rank computed
 //   per task: u32 id | u32 nfiles | nfiles x { u32 adler32, u64 posblock, u64 size } | u32 nblocks | nblocks x u64 size | u64 len | bytes
 constexpr uint32_t kShardMagic = 0x53415343u;
 
@@ -1304,8 +1308,9 @@ int CSA_Add(const char *arcname, const char *const *filenames, int nfilenames, c
 // data ~2.2 x faster than binary / delta data), each task to the rank with the least cost so far (ties: lowest rank).  The deal is
 // a schedule, not data: the archive is the same whatever it is (tasks are appended in id order).  CSA_DEAL=mod restores round 3's
 // `task i -> rank i mod world`.
-double task_cost_factor(const Task &t)
+static double task_cost_factor(const Task &t, int level)
 {
+    if (level != 3) return 1.0;                     // (the factors are level-3 measurements: other levels deal by size alone)
     for (const FilePiece &f : t.files) {
         if (!f.size) continue;
         int fd = open(f.path.c_str(), O_RDONLY);
@@ -1321,13 +1326,13 @@ double task_cost_factor(const Task &t)
     }
     return 1.0;
 }
-void deal_tasks(const std::vector<Task> &tasks, int world, std::vector<uint32_t> &rank_of, std::vector<double> &cost)
+static void deal_tasks(const std::vector<Task> &tasks, int world, int level, std::vector<uint32_t> &rank_of, std::vector<double> &cost)
 {
     const size_t nt = tasks.size();
     rank_of.assign(nt, 0); cost.assign(nt, 0.0);
     const char *mode = getenv("CSA_DEAL");
     const bool mod = mode && !strcmp(mode, "mod");
-    for (size_t i = 0; i < nt; i++) cost[i] = (double)tasks[i].total * (mod ? 1.0 : task_cost_factor(tasks[i]));
+    for (size_t i = 0; i < nt; i++) cost[i] = (double)tasks[i].total * (mod ? 1.0 : task_cost_factor(tasks[i], level));
     if (mod || world <= 1) { for (size_t i = 0; i < nt; i++) rank_of[i] = (uint32_t)(i % (size_t)std::max(1, world)); return; }
     std::vector<uint32_t> order(nt);
     for (size_t i = 0; i < nt; i++) order[i] = (uint32_t)i;
@@ -1348,7 +1353,7 @@ int CSAMI_PlanShards(const char *const *filenames, int nfilenames, const CSAOpti
     if (int prc = plan_add(P, filenames, nfilenames, opt)) return prc < 0 ? prc : -prc;
     std::vector<uint32_t> ro;
     std::vector<double> co;
-    deal_tasks(P.tasks, world, ro, co);
+    deal_tasks(P.tasks, world, opt ? opt->level : 2, ro, co);
     for (size_t i = 0; i < ro.size() && i < cap; i++) { if (rank_of) rank_of[i] = ro[i]; if (cost) cost[i] = co[i]; }
     return (int)ro.size();
 }
@@ -1367,13 +1372,20 @@ int CSAMI_AddShardEncode(const char *const *filenames, int nfilenames, const CSA
     std::vector<uint32_t> ids;
     std::vector<uint32_t> rank_of;
     std::vector<double> cost;
-    deal_tasks(P.tasks, world, rank_of, cost);
+    deal_tasks(P.tasks, world, opt ? opt->level : 2, rank_of, cost);
     for (size_t i = 0; i < P.tasks.size(); i++)
         if ((int)rank_of[i] == rank) { mine.push_back(P.tasks[i]); ids.push_back((uint32_t)i); }   // (id order within a rank = dispatch order, csarc.cpp:355)
     std::vector<uint8_t> out;
     put_le(out, kShardMagic, 4);
     put_le(out, P.tasks.size(), 4);
     put_le(out, mine.size(), 4);
+    {
+        // every rank computes the deal by itself (first 8 KiB of files, CSA_DEAL): a hash of it travels with the blob so that ranks that
+        // disagreed are told apart from a damaged blob at assembly
+        uint32_t h = 2166136261u ^ (uint32_t)world;
+        for (uint32_t r : rank_of) h = (h ^ r) * 16777619u;
+        put_le(out, h, 4);
+    }
     int rc = encode_tasks(mine, [&](size_t k, BlockSink &s) {
         put_le(out, ids[k], 4);
         put_le(out, mine[k].files.size(), 4);
@@ -1407,12 +1419,16 @@ int CSAMI_AddShardAssemble(const char *arcname, const char *const *filenames, in
     std::vector<Part> parts(P.tasks.size(), Part{nullptr, nullptr, nullptr, 0, 0, 0});
     for (int b = 0; b < nblobs; b++) {
         const uint8_t *p = blobs[b], *end = p + blob_lens[b];
-        if (blob_lens[b] < 12 || load_le(p, 4) != kShardMagic || load_le(p + 4, 4) != P.tasks.size()) {
+        if (blob_lens[b] < 16 || load_le(p, 4) != kShardMagic || load_le(p + 4, 4) != P.tasks.size()) {
             fprintf(stderr, "csa-mi355x: shard %d does not belong to this plan (input changed between ranks?)\n", b);
             return -1;
         }
+        if (b > 0 && load_le(p + 12, 4) != load_le(blobs[0] + 12, 4)) {
+            fprintf(stderr, "csa-mi355x: shards 0 and %d were encoded under different task -> rank deals (the ranks disagreed: CSA_DEAL, or a file's first block, differs between them)\n", b);
+            return -3;
+        }
         uint32_t n = (uint32_t)load_le(p + 8, 4);
-        p += 12;
+        p += 16;
         for (uint32_t k = 0; k < n; k++) {
             if (end - p < 8) return -1;
             uint32_t id = (uint32_t)load_le(p, 4), nf = (uint32_t)load_le(p + 4, 4);

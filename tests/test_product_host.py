@@ -120,3 +120,18 @@ def test_bench_summary_is_compact_and_carries_the_other_configs():
     s = b.summary_of(line)
     assert len(json.dumps(s)) <= 600
     assert s["m5"] == [0.57, 9e-6, 4.5, True] and s["m2"][0] == 2.6 and s["p8"][0] == 17.1 and s["p954"][0] == 465.0 and s["p954_dec"] == [670.0, True]
+
+
+def test_library_exports_only_its_api():
+    """a drop-in for libcsc.a must not leak C++ symbols (kernel launch stubs, helpers) into the program it is linked into:
+    the dynamic symbol table holds the C API -- CSCEnc* / CSCDec* / CSCEncProps_* (the reference's eleven), CSA_*, the CSCMI_* /
+    CSAMI_* extensions -- and nothing else (csc_amd/csrc/exports.map)"""
+    for lib in ("csc_amd/libcsc_mi355x.so", "tests/stage/libcsc_stage.so"):
+        path = os.path.join(ROOT, lib)
+        if not os.path.exists(path):
+            continue
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        names = [l.split()[-1] for l in out.splitlines() if l.strip()]
+        bad = [n for n in names if not re.match(r"^(CSCEnc|CSCDec|CSCEncProps_|CSCMI_|CSA_|CSAMI_|CSCST_)", n)]
+        assert not bad, (lib, bad[:10])
+        assert any(n == "CSCEnc_Encode" for n in names)
