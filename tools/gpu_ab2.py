@@ -28,7 +28,7 @@ def enc_streams(lib, datas, level, dict_size, batch=False):
     L = lib.lib
     hs, ws, devs = [], [], []
     for d in datas:
-        p = lib.props_init(dict_size, level)
+        p = lib.props_init(dict_size if dict_size else min(64 << 20, max(1, len(d))), level)
         w = BytesWriter()
         h = L.CSCEnc_Create(C.byref(p), C.cast(w.ptr(), C.c_void_p), None)
         assert h
@@ -57,6 +57,7 @@ def enc_streams(lib, datas, level, dict_size, batch=False):
 
 
 WORK = {"m3": ("enwik9", 3, 64 << 20, 1), "p8": ("enwik9", 3, 64 << 20, 8), "m5": ("silesia.tar", 5, 256 << 20, 1), "m2": ("mix5", 2, 1 << 30, 1),
+        "s954": ("enwik9", 3, 64 << 20, 954),          # the whole stand-in as 954 task streams of ~1 MB, one batch launch (the one-wavefront form: > kD4MultiMax streams)
         "m3b": ("enwik9", 3, 64 << 20, 1), "m5b": ("silesia.tar", 5, 256 << 20, 1), "m2b": ("mix5", 2, 1 << 30, 1)}      # ..b: one stream through the batch call (the multi instance of the kernel)
 mib = int(os.environ.get("AB_MIB", "4"))
 streams_for_dec = {}
@@ -65,11 +66,15 @@ for wk in what:
         continue
     cname, level, dsz, ns = WORK[wk]
     src = corpus.Source(cname)
-    datas = [src.read(i * (100 << 20), mib << 20).tobytes() for i in range(ns)]
+    if wk == "s954":
+        from csc_amd import corpus as _c
+        datas = [src.read(off, n).tobytes() for off, n in _c.task_slices(src.size, ns)]
+    else:
+        datas = [src.read(i * (100 << 20), mib << 20).tobytes() for i in range(ns)]
     res = {n: [] for n in names}; dig = {}
     for rep in range(int(os.environ.get("AB_REPS", "3"))):
         for n in names:
-            dt, outs = enc_streams(libs[n], datas, level, dsz, batch=wk.endswith("b"))
+            dt, outs = enc_streams(libs[n], datas, level if wk != "s954" else level, dsz if wk != "s954" else None, batch=wk.endswith("b"))
             res[n].append(sum(len(d) for d in datas) / 1e6 / dt)
             dig[n] = hashlib.sha256(b"".join(outs)).hexdigest()[:12]
             if wk in ("m3", "m2") and n == names[0]:
