@@ -60,7 +60,6 @@ __device__ static const uint32_t kDltIndex[5] = {1, 2, 3, 4, 8};   // csc_typede
 // LDS image of one stream while k_encode_runs is resident (< 40 KiB: four streams per CU fit in 160 KiB)
 constexpr uint32_t kTokRing = 2048;
 constexpr uint32_t kDpWaves = 4;          // parse wavefronts per stream the advanced parser can use (csc_kernels_dp2.inc)
-constexpr uint32_t kDpChainWaves = 8;     // chain wavefront + seven workers (csc_kernels_dp3.inc): launches with few streams
 // Advanced parser on two parse wavefronts (csc_kernels_dp2.inc): what the wavefront that visited DP node k leaves for the
 // visitor of node k + 1, and the control words of a DP window.
 struct DpEdge {
@@ -798,7 +797,6 @@ DEV void sc_load_regs(Sc &c, EncState *S, EncLds *L);   // csc_kernels_blocks.in
 #include "csc_kernels_mf.inc"
 #include "csc_kernels_lz.inc"
 #include "csc_kernels_dp2.inc"
-#include "csc_kernels_dp3.inc"
 #if CSCMI_TU != 1
 #include "csc_kernels_bt.inc"
 #include "csc_kernels_hp.inc"

@@ -126,9 +126,9 @@ def test_level3_long_runs_of_windows_that_end_at_their_first_node(prod, orc, zal
 
 
 def test_advanced_parser_wavefront_counts(prod, orc, zalloc):
-    """The advanced parser of the hash-table levels picks its form by how many streams a launch carries: <= 128 the chain form
-    (eight wavefronts: chain + seven workers, csc_kernels_dp3.inc), <= 256 four parse wavefronts taking nodes in turn
-    (csc_kernels_dp2.inc), <= 512 the same in the 256-VGPR instance (two workgroups a CU), above that one wavefront.
+    """The advanced parser of the hash-table levels picks its form by configuration and by how many streams a launch carries: the
+    level-3 geometry up to 768 streams the pipeline form (twelve wavefronts a stream, csc_kernels_dp4.inc), everything else -- level 4,
+    more streams -- one wavefront a stream (round 6 retired the chain and turn-taking forms that used to serve few level-4 streams).
     Same bytes in every case: batches of 3, 200, 300 and 520 small task streams (mixed text / exe, ragged sizes, some empty)
     against the oracle, at levels 3 and 4."""
     import torch

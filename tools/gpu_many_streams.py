@@ -4,7 +4,7 @@ streams (-m3 -d64m, one batch call per chunk round) through the development buil
   * the product's choice: the pipeline form up to 256 streams, the one-wavefront form (four streams a CU) beyond;
   * CSCMI_D4_MULTI_MAX=4096: the pipeline form for every launch -- 256 streams resident (one twelve-wavefront workgroup a CU), the
     rest start as workgroups end;
-  * CSCMI_DP_WAVES=2 / 4: the turn-taking forms where they apply.
+  (round 5 also compared the turn-taking forms, CSCMI_DP_WAVES=2 / 4: retired in round 6.)
 gpurun -- python tools/gpu_many_streams.py 954 2048   (stream counts)"""
 import ctypes as C, hashlib, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,7 +42,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     sys.exit(0)
 for S in [int(x) for x in sys.argv[1:]] or [954]:
     for label, env in (("product's choice", {}), ("pipeline form for every launch (256 resident)", {"CSCMI_D4_MULTI_MAX": "4096"}),
-                       ("two turn-taking parse wavefronts", {"CSCMI_DP_WAVES": "2"}), ("four turn-taking parse wavefronts", {"CSCMI_DP_WAVES": "4"})):
+                       ):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", str(S)], env=dict(os.environ, **env), capture_output=True, text=True)
         out = [l for l in r.stdout.splitlines() if "streams:" in l]
         print(f"{label:50s} {out[0] if out else 'FAILED ' + r.stderr[-300:]}", flush=True)
