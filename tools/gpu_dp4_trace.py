@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa
 from csc_amd import corpus
 from csc_amd.capi import CscLib, BytesWriter
-lib = CscLib(os.path.join(ROOT, "csc_amd", "csrc", "build", "dev", "libcsc_mi355x_timers.so"))
+lib = CscLib(os.environ.get("CSC_DEV_LIB") or os.path.join(ROOT, "csc_amd", "csrc", "build", "dev", "libcsc_mi355x_timers.so"))      # (the node trace needs the -DCSCMI_TIMERS_FINE build: CSC_DEV_LIB=csc_amd/csrc/build/dev_fine/libcsc_mi355x_timers.so)
 kind = os.environ.get("KIND", "text")
 data = corpus.fill(kind, corpus.SEED_ENWIK9, 0, 2 << 20).tobytes()
 p = lib.props_init(64 << 20, 3)
