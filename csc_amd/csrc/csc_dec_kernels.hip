@@ -140,6 +140,11 @@ DDEV uint32_t next_byte(Dc &c, int kind)
             c.bv[kind] = c.q[kind][(size_t)slot * c.bsize + c.rd[kind] + c.lane];   // ring has 64 bytes of slack
         }
         c.woff[kind] = 0;
+        // The wait for these 64 bytes belongs HERE, once per refill: left to the compiler it lands in front of the v_readlane below, on the path every byte takes
+        // (the refill joins it there), as s_waitcnt vmcnt(0) -- and on this target a wavefront's window STORES count in vmcnt until the L2 has acknowledged them:
+        // every renormalisation then waited for the last literal's store to come back.  The asm takes the loaded register in and out: what the path below reads
+        // is no longer the result of a load.
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(c.bv[kind]));
     }
     uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)c.bv[kind], (int)c.woff[kind]);
     c.woff[kind]++;
@@ -588,8 +593,29 @@ DNOINL void dlz_fast()
     // byte that follows as context.  With no copy pending pv is the context byte in every lane.
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)c.wnd, 0, (int)(c.wnd_size + 256u), 0x00020000);
     uint32_t pv = c.ctx, p_n = 0, p_to = 0, p_last = 0;
+    // Development A/B (tools/ab_variant_dec.sh, profiles/r06_dec_two_wave.md): DEC_AB_COPY2 (= DEC_AB_LIT2 + DEC_AB_MATCH2: the literals' stores / the copies' loads and stores) issues every window store / copy load of this loop a second
+    // time (same bytes, same places: the output stands) -- what the window work costs THIS wavefront in issue slots, i.e. the most a second wavefront that owned
+    // the window could take off it; DEC_AB_TOKEN adds what such a split would add instead: a token and a count into LDS per packet.
+#ifdef DEC_AB_COPY2
+#define DEC_AB_LIT2
+#define DEC_AB_MATCH2
+#endif
+#ifdef DEC_AB_TOKEN
+    __shared__ uint32_t ab_tok[128][2];
+    __shared__ uint32_t ab_head;
+    uint32_t ab_n = 0;
+#define DEC_AB_PUSH(x, y) do { *(volatile __attribute__((address_space(3))) uint32_t *)&ab_tok[ab_n & 127u][0] = (x); *(volatile __attribute__((address_space(3))) uint32_t *)&ab_tok[ab_n & 127u][1] = (y); ab_n++; *(volatile __attribute__((address_space(3))) uint32_t *)&ab_head = ab_n; } while (0)
+#else
+#define DEC_AB_PUSH(x, y) do {} while (0)
+#endif
     auto flush = [&]() {
         __builtin_amdgcn_raw_buffer_store_b8((uint8_t)pv, wr, (int)(c.lane < p_n ? p_to + c.lane : 0xFFFFFFFFu), 0, 0);
+#if defined(DEC_AB_MATCH2) || defined(DEC_AB_CLOB)
+        asm volatile("" ::: "memory");
+#endif
+#ifdef DEC_AB_MATCH2
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)pv, wr, (int)(c.lane < p_n ? p_to + c.lane : 0xFFFFFFFFu), 0, 0);
+#endif
         p_n = 0;
     };
     for (;;) {
@@ -626,6 +652,13 @@ DNOINL void dlz_fast()
             ltop = *(volatile __attribute__((address_space(3))) uint16_t *)&c.L->plit[lrow + (c.lane & 15)];
             dbyte_low_update<1>(c, lo);
             c.wnd[c.wnd_pos] = (uint8_t)b;          // (every lane the same byte to the same place)
+#if defined(DEC_AB_LIT2) || defined(DEC_AB_CLOB)
+            asm volatile("" ::: "memory");
+#endif
+#ifdef DEC_AB_LIT2
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)b, wr, (int)c.wnd_pos, 0, 0);          // (not a volatile store: that one would wait for its own acknowledgement)
+#endif
+            DEC_AB_PUSH(b, c.wnd_pos);
             c.wnd_pos++;
             n_left--;
             DTM_ADD(c, 2);
@@ -645,6 +678,13 @@ DNOINL void dlz_fast()
         const bool overlap = w.from < c.wnd_pos && w.from + w.len > c.wnd_pos;      // then dist = wnd_pos - from < len
         if (LIKELY(w.len <= 64 && !overlap)) {
             pv = __builtin_amdgcn_raw_buffer_load_b8(wr, (int)(w.from + c.lane), 0, 0);
+#if defined(DEC_AB_MATCH2) || defined(DEC_AB_CLOB)
+            asm volatile("" ::: "memory");
+#endif
+#ifdef DEC_AB_MATCH2
+            pv |= __builtin_amdgcn_raw_buffer_load_b8(wr, (int)(w.from + c.lane), 0, 0);
+#endif
+            DEC_AB_PUSH(w.from, w.len | 0x80000000u);
             p_n = w.len; p_to = c.wnd_pos; p_last = w.len - 1;
         } else {
             pv = dcopy_match(c, w.from, w.dist, w.len);

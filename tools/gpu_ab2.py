@@ -57,6 +57,7 @@ def enc_streams(lib, datas, level, dict_size, batch=False):
 
 
 WORK = {"m3": ("enwik9", 3, 64 << 20, 1), "p8": ("enwik9", 3, 64 << 20, 8), "m5": ("silesia.tar", 5, 256 << 20, 1), "m2": ("mix5", 2, 1 << 30, 1),
+        "t2": ("enwik9", 2, 64 << 20, 1), "t1": ("enwik9", 1, 64 << 20, 1),          # text at the lazy / greedy level (the hp form)
         "s954": ("enwik9", 3, 64 << 20, 954),          # the whole stand-in as 954 task streams of ~1 MB, one batch launch (the one-wavefront form: > kD4MultiMax streams)
         "m3b": ("enwik9", 3, 64 << 20, 1), "m5b": ("silesia.tar", 5, 256 << 20, 1), "m2b": ("mix5", 2, 1 << 30, 1)}      # ..b: one stream through the batch call (the multi instance of the kernel)
 mib = int(os.environ.get("AB_MIB", "4"))

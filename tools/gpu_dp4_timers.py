@@ -67,3 +67,9 @@ if tr[15] and any(tr[0:5]):
 
 if tr[15] and any(tr[32:36]):
     print(f"    straight-line steps left for a general step because: equality bits that cannot answer (mask too old / based ahead / straddling) {tr[32]}, refresh zone {tr[35]}   (general steps in all: {tr[28]})")
+
+if tr[15] and tr[40]:
+    nw = tr[15]
+    print(f"    queue room asked for (d6_room's slow path) {tr[40]} times ({tr[40]/nw:.2f} a window): join {16*tr[41]/tr[40]:.0f} cycles each, publish + wait for the coder wavefront {16*tr[42]/tr[40]:.0f} each ({16*(tr[41]+tr[42])/nw:.0f} a window), room afterwards {16*tr[46]/tr[40]:.0f} entries")
+if tr[15] and tr[44]:
+    print(f"    coder wavefront: {tr[44]} queue entries in {tr[45]} batches, {16*tr[43]/tr[44]:.0f} cycles an entry, busy {16*tr[43]/tr[15]:.0f} cycles a window")
