@@ -144,7 +144,9 @@ DDEV uint32_t next_byte(Dc &c, int kind)
         // (the refill joins it there), as s_waitcnt vmcnt(0) -- and on this target a wavefront's window STORES count in vmcnt until the L2 has acknowledged them:
         // every renormalisation then waited for the last literal's store to come back.  The asm takes the loaded register in and out: what the path below reads
         // is no longer the result of a load.
+#ifndef DEC_NO_REFILL_WAIT
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(c.bv[kind]));
+#endif
     }
     uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)c.bv[kind], (int)c.woff[kind]);
     c.woff[kind]++;
@@ -676,7 +678,11 @@ DNOINL void dlz_fast()
         // the packet's copy (every kind that comes here has one)
         flush();
         const bool overlap = w.from < c.wnd_pos && w.from + w.len > c.wnd_pos;      // then dist = wnd_pos - from < len
+#ifdef DEC_DBG_NODEFER
+        if (false) {                     // (development: every copy at once, none deferred)
+#else
         if (LIKELY(w.len <= 64 && !overlap)) {
+#endif
             pv = __builtin_amdgcn_raw_buffer_load_b8(wr, (int)(w.from + c.lane), 0, 0);
 #if defined(DEC_AB_MATCH2) || defined(DEC_AB_CLOB)
             asm volatile("" ::: "memory");
@@ -714,7 +720,11 @@ DDEV void dlz_decode(Dc &c, uint32_t limit)
     uint32_t i = c.i, copied = c.copied, copied_from = c.copied_from;
     Ck k;
     for (; i <= limit;) {
+#ifdef DEC_DBG_CAREFUL
+        const bool zone = true;          // (development: every packet the checkpointed way, dlz_fast never runs)
+#else
         const bool zone = dlz_careful_zone(c);
+#endif
         bool end = false;
         if (LIKELY(!zone)) {
             DecHand &H = c.L->hand;

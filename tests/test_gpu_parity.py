@@ -38,6 +38,22 @@ def test_stream_matches_reference_vector(prod, key):
     assert prod.decode(s) == (0, data)
 
 
+def test_a_stream_the_reference_does_not_turn_back_into_its_input_is_reproduced(prod):
+    """tests/golden/ref_roundtrip_hazard.json (recorded from the reference, tools/make_golden_ref_roundtrip.py; found by tools/gpu_soak.py): the reference's one-byte
+    rep match reads wnd_[wnd_size_], which the decoder never writes, when wnd_curpos_ == rep_dist_[0] (csc_dec.cpp:525-527); under a zeroing allocator its decoder
+    turns the reference's own stream for this input into bytes that differ from the input in nine places, with return code 0.  The HIP encoder must write that
+    stream and the HIP decoder (window and slack zeroed at Create) must return those bytes -- parity with the reference, not with the input."""
+    import hashlib
+    gold = json.load(open(os.path.join(G, "ref_roundtrip_hazard.json")))
+    data = cases.build(gold["spec"])
+    assert hashlib.sha256(data).hexdigest() == gold["input_sha256"]
+    rc, s = prod.encode(data, props=prod.props_init(gold["dict"], gold["level"]))
+    assert rc == 0 and len(s) == gold["stream_bytes"] and hashlib.sha256(s).hexdigest() == gold["stream_sha256"]
+    rcd, back = prod.decode(s)
+    assert rcd == gold["decoded_rc"] and hashlib.sha256(back).hexdigest() == gold["decoded_sha256"]
+    assert [[i, data[i], back[i]] for i in range(len(data)) if data[i] != back[i]] == gold["decoded_differs_from_input_at"]
+
+
 @pytest.mark.parametrize("level", [1, 2, 3, 4, 5])
 def test_against_oracle_on_fresh_inputs(prod, orc, zalloc, level):
     data = cases.build([["text", 100 + level, 12345, 400000], ["exe", 200 + level, 777, 250000],

@@ -147,3 +147,19 @@ def test_oracle_pos_renormalisation_matches_the_reference(orc, zalloc, level):
     assert len(got) == want["stream_bytes"] and hashlib.sha256(got).hexdigest() == want["sha256"]
     rc, plain = orc.encode(data, props=props, alloc=zalloc)
     assert rc == 0 and plain == got
+
+
+def test_oracle_reproduces_a_stream_the_reference_does_not_turn_back_into_its_input(orc, zalloc):
+    """tests/golden/ref_roundtrip_hazard.json (tools/make_golden_ref_roundtrip.py, found by tools/gpu_soak.py): the REFERENCE's one-byte rep match reads wnd_[wnd_size_] -- a byte the
+    decoder never writes -- when wnd_curpos_ == rep_dist_[0] (csc_dec.cpp:525-527: `>` where every other copy has `>=`); under the zeroing allocator of all our
+    vectors its decoder, fed the reference's own stream for this input, returns 0 and nine bytes that are not the input's.  Parity is with the reference: the
+    restatement writes the same stream and decodes it into the same bytes -- wrong in the same nine places."""
+    import hashlib
+    gold = json.load(open(os.path.join(G, "ref_roundtrip_hazard.json")))
+    data = cases.build(gold["spec"])
+    assert hashlib.sha256(data).hexdigest() == gold["input_sha256"]
+    rc, s = orc.encode(data, props=orc.props_init(gold["dict"], gold["level"]), alloc=zalloc)
+    assert rc == 0 and len(s) == gold["stream_bytes"] and hashlib.sha256(s).hexdigest() == gold["stream_sha256"]
+    rcd, back = orc.decode(s, alloc=zalloc)
+    assert rcd == gold["decoded_rc"] and hashlib.sha256(back).hexdigest() == gold["decoded_sha256"]
+    assert [[i, data[i], back[i]] for i in range(len(data)) if data[i] != back[i]] == gold["decoded_differs_from_input_at"]
