@@ -38,6 +38,20 @@ def test_stream_matches_reference_vector(prod, key):
     assert prod.decode(s) == (0, data)
 
 
+@pytest.mark.parametrize("name", sorted(json.load(open(os.path.join(G, "soak_cases.json")))))
+def test_level3_ids_are_looked_after_in_short_windows(prod, name):
+    """tests/golden/soak_cases.json (the reference's streams, tools/make_golden_soak_cases.py; found by tools/gpu_soak_batch.py in round 6): long runs of literals
+    between two- and three-byte matches -- every DP window ends at its first node or is skipped.  The level-3 form used to drop the re-based ids of its rep
+    distances on that way out; 256 positions on the candidate entry behind a live id was recycled and the stream could not be decoded."""
+    import hashlib
+    gold = json.load(open(os.path.join(G, "soak_cases.json")))[name]
+    data = cases.build(gold["spec"])
+    assert hashlib.sha256(data).hexdigest() == gold["input_sha256"]
+    rc, s = prod.encode(data, props=prod.props_init(gold["dict"], gold["level"]))
+    assert rc == 0 and len(s) == gold["stream_bytes"] and hashlib.sha256(s).hexdigest() == gold["stream_sha256"]
+    assert prod.decode(s) == (0, data)
+
+
 def test_a_stream_the_reference_does_not_turn_back_into_its_input_is_reproduced(prod):
     """tests/golden/ref_roundtrip_hazard.json (recorded from the reference, tools/make_golden_ref_roundtrip.py; found by tools/gpu_soak.py): the reference's one-byte
     rep match reads wnd_[wnd_size_], which the decoder never writes, when wnd_curpos_ == rep_dist_[0] (csc_dec.cpp:525-527); under a zeroing allocator its decoder

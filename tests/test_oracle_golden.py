@@ -163,3 +163,15 @@ def test_oracle_reproduces_a_stream_the_reference_does_not_turn_back_into_its_in
     rcd, back = orc.decode(s, alloc=zalloc)
     assert rcd == gold["decoded_rc"] and hashlib.sha256(back).hexdigest() == gold["decoded_sha256"]
     assert [[i, data[i], back[i]] for i in range(len(data)) if data[i] != back[i]] == gold["decoded_differs_from_input_at"]
+
+
+@pytest.mark.parametrize("name", sorted(json.load(open(os.path.join(G, "soak_cases.json")))))
+def test_oracle_on_the_cases_a_soak_once_found_the_hip_path_wrong_on(orc, zalloc, name):
+    """tests/golden/soak_cases.json (tools/make_golden_soak_cases.py: the reference's streams): the restatement writes them too."""
+    import hashlib
+    gold = json.load(open(os.path.join(G, "soak_cases.json")))[name]
+    data = cases.build(gold["spec"])
+    assert hashlib.sha256(data).hexdigest() == gold["input_sha256"]
+    rc, s = orc.encode(data, props=orc.props_init(gold["dict"], gold["level"]), alloc=zalloc)
+    assert rc == 0 and len(s) == gold["stream_bytes"] and hashlib.sha256(s).hexdigest() == gold["stream_sha256"]
+    assert orc.decode(s, alloc=zalloc) == (0, data)

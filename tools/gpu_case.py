@@ -32,6 +32,9 @@ for nm in names:
     rc, s = L.encode(data, props=mk(L))
     first = next((i for i in range(min(len(s), len(want))) if s[i] != want[i]), None)
     rcd, back = L.decode(s) if rc == 0 else (rc, b"")
+    if "--save" in flags:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        open(os.path.join(ROOT, "gpurun_out", f"case_{nm}.bin"), "wb").write(s); open(os.path.join(ROOT, "gpurun_out", "case_ref.bin"), "wb").write(want)
     if rc == 0 and back != data:
         bad = [i for i in range(min(len(back), len(data))) if back[i] != data[i]]
         print(f"    decoded {len(back)} B of {len(data)}; {len(bad)} bytes differ, first at {bad[0] if bad else None} (= {bad[0] / (1 << 20) if bad else 0:.4f} MiB), last at {bad[-1] if bad else None}; runs: "

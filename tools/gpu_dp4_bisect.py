@@ -14,8 +14,10 @@ lib = CscLib(os.path.join(ROOT, "csc_amd", "csrc", "build", "dev", "libcsc_mi355
 orc = CscLib(os.path.join(ROOT, "oracle", "liborc.so"))
 orc.lib.orc_zero_alloc.restype = C.c_void_p
 za = orc.lib.orc_zero_alloc()
-data = corpus.fill("text", corpus.SEED_ENWIK9, boff, mib << 20).tobytes()
-p = lib.props_init(64 << 20, 3)
+# (KIND / NBYTES / DICT in the environment: another corpus kind, a byte count instead of MiB, another dictionary size -- a case of tools/gpu_soak.py)
+data = corpus.fill(os.environ.get("KIND", "text"), corpus.SEED_ENWIK9, boff, int(os.environ.get("NBYTES", mib << 20))).tobytes()
+p = lib.props_init(int(os.environ.get("DICT", 64 << 20)), 3)
+if os.environ.get("NOFILTERS"): p.DLTFilter = 0; p.TXTFilter = 0; p.EXEFilter = 0
 rc2, want = orc.encode(data, props=p, alloc=za)
 lib.lib.CSCMI_EncodeHostChunk.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
 lib.lib.CSCMI_DebugSetMask.argtypes = [C.c_void_p, C.c_uint64]
@@ -42,7 +44,13 @@ for mask in masks:
         for l in range(4):
             a, b, cc = tr[60 * 12 + 3 * l], tr[60 * 12 + 3 * l + 1], tr[60 * 12 + 3 * l + 2]
             if cc: print(f"  old id: rep {l} at sub-block position {a & 0xFFFFFFFF} (node {a >> 32}): id {b & 0xFFFFFFFF} age {cc} fwd {b >> 32:#x}")
-    if tr[62 * 12] == 2:
+    if tr[62 * 12] == 7:
+        r = list(tr[62 * 12: 62 * 12 + 12]); u = list(tr[63 * 12: 63 * 12 + 12])
+        print(f"  window at stream position {r[1]}: kind {r[2]} end {r[3]} a0l {r[4]} a0code {r[5]} a0slot {r[6]}; exit label's rep distances {r[7:11]} state-at-start {r[11]}; L->rep at window start {u[1:5]} rid {u[7] & 0xFFFFFFFF:#x} {u[7] >> 32:#x} {u[8] & 0xFFFFFFFF:#x} {u[8] >> 32:#x}; fwd[rid0] {u[9]:#x} base of rid0's mask {u[10]} rq head/tail {u[11] & 0xFFFFFFFF}/{u[11] >> 32}")
+        for q in range(0, min(60, r[3] + 1)):
+            dcode, bk = tr[q * 12], tr[q * 12 + 1]
+            print(f"    node {q:2d}: dist code {dcode:6d} back {bk & 0xFFFF:3d} state {(bk >> 16) & 0x3F:2d}")
+    elif tr[62 * 12] == 2:
         r = list(tr[62 * 12: 62 * 12 + 12])
         print(f"  length-price table differs after the window at {r[1]}: split {r[2]:#x} alone {r[3]:#x}; lp at open {r[4]} after {r[5]} end {r[6]}")
     elif tr[62 * 12]:
